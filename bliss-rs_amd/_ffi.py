@@ -1,0 +1,92 @@
+"""ctypes binding of libblissgpu.so (the C ABI declared in include/blissgpu.h).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is usable, every compute
+call raises.  The library is loaded lazily so that `import bliss_rs_amd` (and the build check) works
+on a machine without a GPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblissgpu.so")
+
+OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_OOM = 0, 1, 2, 3, 4
+SONG_OK, SONG_TOO_SHORT = 0, 1
+METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_MAHALANOBIS = 0, 1, 2
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/blissgpu.h declares
+SIGNATURES = {
+    "blissgpu_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "blissgpu_ctx_destroy": (C.c_int, [_vp]),
+    "blissgpu_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "blissgpu_ctx_get_stream": (_vp, [_vp]),
+    "blissgpu_ctx_set_workspace_limit": (C.c_int, [_vp, C.c_uint64]),
+    "blissgpu_ctx_synchronize": (C.c_int, [_vp]),
+    "blissgpu_feature_count": (C.c_uint32, [C.c_uint32]),
+    "blissgpu_analyze": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _i32p]),
+    "blissgpu_analyze_batch": (C.c_int, [_vp, _u64p, _u64p, C.c_uint32, C.c_uint32, _vp, _i32p]),
+    "blissgpu_analyze_batch_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, C.c_uint32, _vp, _vp]),
+    "blissgpu_distance": (C.c_int, [_vp, _vp, C.c_uint32, C.c_int, _vp, _f32p]),
+    "blissgpu_pairwise": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp]),
+    "blissgpu_pairwise_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp,
+                                           C.c_uint64]),
+    "blissgpu_feature_weights": (C.c_int, [C.c_uint32, _vp]),
+    "blissgpu_malloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
+    "blissgpu_free": (C.c_int, [_vp]),
+    "blissgpu_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "blissgpu_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "blissgpu_synth_white_noise_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, C.c_uint32]),
+    "blissgpu_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "blissgpu_profile_reset": (C.c_int, [_vp]),
+    "blissgpu_profile_kernel_count": (C.c_int, []),
+    "blissgpu_profile_kernel_name": (C.c_char_p, [C.c_int]),
+    "blissgpu_profile_get": (C.c_int, [_vp, C.c_int, _f64p, _u64p]),
+    "blissgpu_debug_last_tuning": (C.c_int, [_vp, _f64p, _u32p, C.c_uint32]),
+    "blissgpu_debug_fetch": (C.c_int, [_vp, C.c_int, C.c_uint32, _vp, C.c_uint64, _u64p]),
+    "blissgpu_strerror": (C.c_char_p, [C.c_int]),
+    "blissgpu_last_error": (C.c_char_p, []),
+    "blissgpu_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class BlissGpuError(RuntimeError):
+    def __init__(self, code, detail):
+        super().__init__(f"blissgpu error {code}: {detail}")
+        self.code = code
+
+
+def lib():
+    """Load libblissgpu.so (fails loudly when the HIP extension has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:  # share torch's HIP runtime instance when torch is around (same SONAME libamdhip64.so.7)
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the C ABI
+            pass
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        L = lib()
+        detail = L.blissgpu_last_error().decode() or L.blissgpu_strerror(rc).decode()
+        raise BlissGpuError(rc, detail)

@@ -1,0 +1,160 @@
+// internal.hpp -- shared declarations of the MI355X analysis library (not part of the C ABI).
+//
+// Vocabulary follows the reference (bliss-rs): songs, frames, descriptors, features.
+//   timbral frames : PVoc windows, W=512 hop=128   (src/timbral.rs:40-41, src/aubio.rs:182-264)
+//   tempo frames   : PVocTempo windows, W=512 hop=256 (src/temporal.rs:40-41, src/aubio.rs:338-425)
+//   chroma frames  : STFT windows, W=8192 hop=2205 (src/chroma.rs:39,74, src/utils.rs:26-64)
+//   loudness chunks: 1024 samples                  (src/misc.rs:44)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bg {
+
+constexpr uint32_t SAMPLE_RATE = 22050;   // src/lib.rs:140
+constexpr int W512 = 512;                 // SpectralDesc::WINDOW_SIZE / BPMDesc::WINDOW_SIZE
+constexpr int HOP_T = 128;                // SpectralDesc::HOP_SIZE
+constexpr int HOP_B = 256;                // BPMDesc::HOP_SIZE
+constexpr int W8192 = 8192;               // ChromaDesc::WINDOW_SIZE
+constexpr int HOP_C = 2205;               // src/chroma.rs:74
+constexpr int CBINS = W8192 / 2 + 1;      // 4097
+constexpr int CBINS_PAD = 4112;           // row pitch (multiple of 16 bins) of the stored spectrogram and of the filter bank
+constexpr int BANK_ROWS = 16;             // 12 chroma rows padded to the MFMA M=16
+constexpr int LOUD_W = 1024;              // LoudnessDesc::WINDOW_SIZE
+constexpr int MIN_SAMPLES = 8192;         // src/song/mod.rs:417-430
+constexpr int N_TUNING = 100;             // pitch_tuning histogram bins at resolution 0.01
+constexpr int PIP_LO = 57, PIP_HI = 1483; // centre bins visited by pip_track at n_fft=8192 (chroma.rs:302-313)
+constexpr int PIP_MAX_PER_FRAME = 714;    // peaks cannot be adjacent: ceil(1427/2)
+constexpr int H1_BINS = 8192;             // coarse magnitude histogram: f32 bit pattern >> 18
+constexpr int BT_WINLEN = 512, BT_STEP = 128, BT_LAGLEN = 128;  // src/aubio.rs:1337-1341, 920-922
+constexpr int F512_TILE = 64;             // timbral frames per workgroup in the FFT-512 kernel
+constexpr int CH_TILE = 64;               // chroma frames per workgroup in the contraction kernel
+
+// Per-song descriptor, built on the host, read by every kernel.
+struct SongDesc {
+    uint64_t pcm_off;   // first sample of the song in the batch PCM buffer
+    uint64_t n;         // samples
+    uint64_t t_off;     // first timbral frame in the batch-wide series arrays
+    uint64_t b_off;     // first tempo frame
+    uint64_t c_off;     // first chroma frame
+    uint64_t e_off;     // first 256-sample energy block
+    uint64_t cand_off;  // first slot of the song's tuning-candidate list
+    uint32_t n_t;       // timbral frames   floor((n-512)/128)+1
+    uint32_t n_b;       // tempo frames     floor((n-512)/256)+1
+    uint32_t n_f;       // FFT-512 frames actually computed = max(n_t, 2*n_b)
+    uint32_t n_c;       // chroma frames    min(ceil_f32(n/2205), n/2205+1)
+    uint32_t n_e;       // 256-sample blocks ceil(n/256)
+    uint32_t n_l;       // loudness chunks  ceil(n/1024)
+    uint32_t row;       // output row
+    uint32_t ok;        // 1 = analyse, 0 = too short (status already set by the host)
+};
+
+// Per-song scalars produced by the tuning stage.
+struct TuningState {
+    uint32_t n_peaks;      // total pip_track peaks
+    uint32_t b_lo, b_hi;   // coarse bins holding the two middle order statistics
+    uint32_t below;        // peaks in coarse bins < b_lo
+    uint32_t n_cand;       // candidates appended so far
+    int32_t tuning_idx;    // argmax bin (first max); tuning = -0.5 + 0.01*idx ; -1 => tuning 0.0 (no peaks)
+    uint32_t pad0, pad1;
+};
+
+// Beat-tracker result per song
+struct TempoState {
+    float tempo;        // normalised feature
+    uint32_t n_bpms;
+};
+
+struct DeviceTables {   // constant tables, built once per context
+    const float2* tw8192;     // exp(-2*pi*i*k/8192), k < 8192
+    const float2* tw512;      // exp(-2*pi*i*k/512),  k < 512
+    const float* hann8192;    // periodic Hann, src/utils.rs:37-39
+    const float* hannz512;    // hanningz, src/aubio.rs:151-154
+    const double* chroma_bank;// [N_TUNING+1][BANK_ROWS][CBINS_PAD] chroma filters (zero padded); slot N_TUNING = tuning 0.0
+    const float* bt_rwv;      // [128] Rayleigh weighting, src/aubio.rs:925-930
+    const float* bt_dfwv;     // [512] detection-function weighting, src/aubio.rs:933-936
+};
+
+enum KernelId : int {
+    K_PCM_STATS = 0,
+    K_FFT512,
+    K_ONSET,
+    K_BEAT,
+    K_STFT8192,
+    K_TUNE_SELECT,
+    K_TUNE_PASS2,
+    K_TUNE_FINAL,
+    K_CHROMA,
+    K_FINALIZE,
+    K_PAIRWISE,
+    K_SYNTH,
+    K_COUNT
+};
+
+// lower_bound on a prefix array: largest s with prefix[s] <= x  (prefix has n+1 entries, prefix[0]=0)
+__device__ __forceinline__ uint32_t find_segment(const uint32_t* __restrict__ prefix, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (prefix[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- launchers (one per .hip file) ----
+struct Workspace {
+    // timbral series [total_t]
+    float *centroid, *rolloff, *flatness;
+    // tempo [total_b]
+    float *flux, *thresholded;
+    // 256-sample energy blocks [total_e], zero-crossings per block
+    float* e256;
+    uint32_t* zc256;
+    // chroma
+    float* spec;            // [total_c][CBINS_PAD] magnitudes (f32, exactly what the reference widens to f64)
+    float* frame_max;       // [total_c]
+    uint32_t* h1;           // [n_songs][H1_BINS]
+    uint32_t* hist100;      // [n_songs][N_TUNING]
+    TuningState* tuning;    // [n_songs]
+    double* cand_mag;       // [total_cand]
+    uint8_t* cand_pb;       // [total_cand]
+    double* chroma_part;    // [total chroma tiles][10] partial sums of interval features
+    TempoState* tempo;      // [n_songs]
+    float* run_bpm;         // [n_songs][runs_pitch] bpm after each beat-tracker run
+    uint32_t* run_cnt;      // [n_songs][runs_pitch] beats recorded while that bpm was current
+    uint32_t runs_pitch;
+};
+
+struct Batch {
+    const float* pcm;
+    const SongDesc* songs;    // device
+    uint32_t n_songs;
+    // tile prefix arrays (device), n_songs+1 entries each
+    const uint32_t* pfx_e;    // pcm-stats tiles
+    const uint32_t* pfx_f;    // fft512 tiles
+    const uint32_t* pfx_c;    // chroma frames
+    const uint32_t* pfx_ct;   // chroma contraction tiles
+    uint32_t tiles_e, tiles_f, tiles_c, tiles_ct;
+    uint64_t total_b;         // tempo frames in the batch
+    uint32_t max_nb;          // longest song's tempo-frame count
+    uint32_t max_nt;          // longest song's timbral-frame count
+};
+
+void launch_pcm_stats(const Batch&, const Workspace&, hipStream_t);
+void launch_fft512(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
+void launch_onset(const Batch&, const Workspace&, hipStream_t);
+void launch_beat(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
+void launch_stft8192(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
+void launch_tune_select(const Batch&, const Workspace&, hipStream_t);
+void launch_tune_pass2(const Batch&, const Workspace&, hipStream_t);
+void launch_tune_final(const Batch&, const Workspace&, hipStream_t);
+void launch_chroma(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
+void launch_finalize(const Batch&, const Workspace&, uint32_t features_version, float* d_out, int32_t* dbg_tuning,
+                     uint32_t* dbg_nbpms, hipStream_t);
+void launch_chroma_bank(double* bank, hipStream_t);
+void launch_pairwise(const float* A, uint64_t n, const float* B, uint64_t m, uint32_t d, int metric, const float* M,
+                     int m_is_diag, float* out, uint64_t ld_out, hipStream_t);
+void launch_synth(float* pcm, const SongDesc* songs, uint32_t n_songs, const uint32_t* pfx_e, uint32_t tiles_e,
+                  uint32_t first_song_index, hipStream_t);
+
+}  // namespace bg

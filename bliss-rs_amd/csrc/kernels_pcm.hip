@@ -1,0 +1,101 @@
+// kernels_pcm.hip -- one coalesced pass over the batch PCM:
+//   * per 256-sample block: sum of squares (feeds LoudnessDesc, src/misc.rs:12-18,46-65, and the
+//     tempo silence test, src/aubio.rs:1258-1276) and zero-crossing count (number_crossings,
+//     src/utils.rs:81-95: a crossing is a change of `x > 0` between consecutive samples)
+//   * Philox4x32-10 white-noise synthesis for the benchmark (no reference counterpart).
+// HBM-bound: 4 bytes read per sample, 8 bytes written per 256 samples.
+#include "device_utils.hpp"
+#include "internal.hpp"
+
+namespace bg {
+
+constexpr int PCM_TILE_BLOCKS = 16;  // 256-sample blocks per workgroup (4 per wave)
+
+__global__ __launch_bounds__(256) void pcm_stats_kernel(const float* __restrict__ pcm,
+                                                        const SongDesc* __restrict__ songs, uint32_t n_songs,
+                                                        const uint32_t* __restrict__ pfx_e, float* __restrict__ e256,
+                                                        uint32_t* __restrict__ zc256) {
+    const uint32_t s = find_segment(pfx_e, n_songs, blockIdx.x);
+    const SongDesc sd = songs[s];
+    const uint32_t tile = blockIdx.x - pfx_e[s];
+    const float* __restrict__ x = pcm + sd.pcm_off;
+    const int lane = lane_id(), wave = wave_id();
+#pragma unroll
+    for (int i = 0; i < PCM_TILE_BLOCKS / 4; i++) {
+        const uint32_t q = tile * PCM_TILE_BLOCKS + wave * (PCM_TILE_BLOCKS / 4) + i;
+        if (q >= sd.n_e) break;  // wave-uniform
+        const uint64_t base = (uint64_t)q * 256;
+        // positivity of the sample before the block (the first sample of the song compares with itself)
+        uint32_t prev_pos = (x[base > 0 ? base - 1 : 0] > 0.0f) ? 1u : 0u;
+        float ss = 0.0f;
+        uint32_t zc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t idx = base + j * 64 + lane;
+            const bool valid = idx < sd.n;
+            const float v = valid ? x[idx] : 0.0f;
+            ss += v * v;
+            const uint64_t pos = __ballot(valid && v > 0.0f);
+            const uint64_t vmask = __ballot(valid);
+            const uint64_t shifted = (pos << 1) | (uint64_t)prev_pos;
+            zc += (uint32_t)__popcll((pos ^ shifted) & vmask);
+            prev_pos = (uint32_t)(pos >> 63);
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) {
+            e256[sd.e_off + q] = ss;
+            zc256[sd.e_off + q] = zc;
+        }
+    }
+}
+
+void launch_pcm_stats(const Batch& b, const Workspace& w, hipStream_t st) {
+    if (b.tiles_e == 0) return;
+    hipLaunchKernelGGL(pcm_stats_kernel, dim3(b.tiles_e), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_e,
+                       w.e256, w.zc256);
+}
+
+// ---- synthetic white noise: uniform [-0.5, 0.5), Philox4x32-10, key = (0x5EED0000 + song, 0),
+// counter = (sample_index / 4, 0, 0, 0); bit-identical to oracle/bliss_oracle.c bo_white_noise ----
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t r[4]) {
+    uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+    for (int round = 0; round < 10; round++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r[0] = c[0]; r[1] = c[1]; r[2] = c[2]; r[3] = c[3];
+}
+
+__global__ __launch_bounds__(256) void synth_kernel(float* __restrict__ pcm, const SongDesc* __restrict__ songs,
+                                                    uint32_t n_songs, const uint32_t* __restrict__ pfx_e,
+                                                    uint32_t first_song_index) {
+    const uint32_t s = find_segment(pfx_e, n_songs, blockIdx.x);
+    const SongDesc sd = songs[s];
+    const uint32_t tile = blockIdx.x - pfx_e[s];
+    float* __restrict__ x = pcm + sd.pcm_off;
+    const uint32_t k0 = 0x5EED0000u + first_song_index + s;
+    // tile = 4096 samples = 1024 Philox blocks, 4 per thread
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint64_t blk = (uint64_t)tile * 1024 + i * 256 + threadIdx.x;
+        const uint64_t idx = blk * 4;
+        if (idx >= sd.n) continue;
+        uint32_t r[4];
+        philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), k0, 0u, r);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (idx + e < sd.n) x[idx + e] = (float)(r[e] >> 8) * (1.0f / 16777216.0f) - 0.5f;
+    }
+}
+
+void launch_synth(float* pcm, const SongDesc* songs, uint32_t n_songs, const uint32_t* pfx_e, uint32_t tiles_e,
+                  uint32_t first_song_index, hipStream_t st) {
+    if (tiles_e == 0) return;
+    hipLaunchKernelGGL(synth_kernel, dim3(tiles_e), dim3(256), 0, st, pcm, songs, n_songs, pfx_e, first_song_index);
+}
+
+}  // namespace bg

@@ -1,0 +1,134 @@
+"""Device-resident API: a blissgpu context driven with torch tensors (torch supplies device memory,
+streams and torch.distributed; the compute is the HIP library)."""
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class Context:
+    """blissgpu_ctx wrapper.  Tensors passed in must live on the context's device."""
+
+    def __init__(self, device: int = 0, use_torch_stream: bool = True):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: bliss_rs_amd has no CPU fallback")
+        self.torch = torch
+        self.device = device
+        torch.cuda.set_device(device)
+        self._L = _ffi.lib()
+        h = C.c_void_p()
+        _ffi.check(self._L.blissgpu_ctx_create(device, C.byref(h)))
+        self._h = h
+        if use_torch_stream:
+            self.bind_current_stream()
+
+    def bind_current_stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        _ffi.check(self._L.blissgpu_ctx_set_stream(self._h, C.c_void_p(s)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.blissgpu_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def synchronize(self):
+        _ffi.check(self._L.blissgpu_ctx_synchronize(self._h))
+
+    def set_workspace_limit(self, nbytes: int):
+        _ffi.check(self._L.blissgpu_ctx_set_workspace_limit(self._h, nbytes))
+
+    # ---- analysis ----
+    def analyze(self, pcm, offsets: Sequence[int], lengths: Sequence[int], features_version: int = 2, out=None,
+                status=None):
+        """pcm: 1-D float32 CUDA tensor holding the songs; returns ([n, d] float32 CUDA tensor, int32 status)."""
+        torch = self.torch
+        assert pcm.is_cuda and pcm.dtype == torch.float32 and pcm.is_contiguous()
+        offsets, lengths = _u64(offsets), _u64(lengths)
+        n = len(offsets)
+        d = 23 if features_version == 2 else 20
+        if out is None:
+            out = torch.empty((n, d), dtype=torch.float32, device=pcm.device)
+        if status is None:
+            status = torch.empty((n,), dtype=torch.int32, device=pcm.device)
+        _ffi.check(self._L.blissgpu_analyze_batch_device(
+            self._h, C.c_void_p(pcm.data_ptr()), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+            lengths.ctypes.data_as(C.POINTER(C.c_uint64)), n, features_version, C.c_void_p(out.data_ptr()),
+            C.c_void_p(status.data_ptr())))
+        return out, status
+
+    def synth_white_noise(self, pcm, offsets, lengths, first_song_index: int = 0):
+        offsets, lengths = _u64(offsets), _u64(lengths)
+        _ffi.check(self._L.blissgpu_synth_white_noise_device(
+            self._h, C.c_void_p(pcm.data_ptr()), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+            lengths.ctypes.data_as(C.POINTER(C.c_uint64)), len(offsets), first_song_index))
+
+    def last_tuning(self, n):
+        t = np.empty(n, np.float64)
+        b = np.empty(n, np.uint32)
+        _ffi.check(self._L.blissgpu_debug_last_tuning(self._h, t.ctypes.data_as(C.POINTER(C.c_double)),
+                                                      b.ctypes.data_as(C.POINTER(C.c_uint32)), n))
+        return t, b
+
+    TAPS = {"centroid": (0, np.float32), "rolloff": (1, np.float32), "flatness": (2, np.float32),
+            "flux": (3, np.float32), "thresholded": (4, np.float32), "run_bpm": (5, np.float32),
+            "run_count": (6, np.uint32), "spectrogram": (7, np.float32), "energy256": (8, np.float32),
+            "crossings256": (9, np.uint32), "pitch_hist": (10, np.uint32)}
+
+    def debug_fetch(self, what: str, song: int) -> np.ndarray:
+        """Intermediate series of one song of the last chunk (per-stage parity tests)."""
+        code, dt = self.TAPS[what]
+        n = C.c_uint64()
+        probe = np.empty(1, dt)
+        _ffi.check(self._L.blissgpu_debug_fetch(self._h, code, song, C.c_void_p(probe.ctypes.data), 0, C.byref(n)))
+        out = np.empty(n.value, dt)
+        if n.value:
+            _ffi.check(self._L.blissgpu_debug_fetch(self._h, code, song, C.c_void_p(out.ctypes.data), n.value, C.byref(n)))
+        if what == "spectrogram":
+            out = out.reshape(-1, 4112)[:, :4097]
+        return out
+
+    # ---- distances ----
+    def pairwise(self, A, B, metric: str = "euclidean", M=None, out=None):
+        torch = self.torch
+        from .playlist import _METRICS
+
+        assert A.is_cuda and B.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32
+        A, B = A.contiguous(), B.contiguous()
+        n, d = A.shape
+        m = B.shape[0]
+        if out is None:
+            out = torch.empty((n, m), dtype=torch.float32, device=A.device)
+        Mp = None
+        if M is not None:
+            M = M.contiguous()
+            Mp = C.c_void_p(M.data_ptr())
+        _ffi.check(self._L.blissgpu_pairwise_device(self._h, C.c_void_p(A.data_ptr()), n, C.c_void_p(B.data_ptr()), m,
+                                                    d, _METRICS[metric], Mp, C.c_void_p(out.data_ptr()), out.stride(0)))
+        return out
+
+    # ---- profiling ----
+    def profile_enable(self, on: bool = True):
+        _ffi.check(self._L.blissgpu_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        _ffi.check(self._L.blissgpu_profile_reset(self._h))
+
+    def profile(self):
+        """{kernel name: (total_ms, launches)} since the last reset."""
+        res = {}
+        for k in range(self._L.blissgpu_profile_kernel_count()):
+            ms, n = C.c_double(), C.c_uint64()
+            _ffi.check(self._L.blissgpu_profile_get(self._h, k, C.byref(ms), C.byref(n)))
+            if n.value:
+                res[self._L.blissgpu_profile_kernel_name(k).decode()] = (ms.value, n.value)
+        return res

@@ -1,0 +1,148 @@
+/*
+ * blissgpu.h -- C ABI of the MI355X-native implementation of bliss-rs's per-song analysis hot path
+ * and feature-vector distances.  This is the drop-in boundary: plain pointers and sizes, no C++/torch
+ * types, no exceptions across the boundary.  Every entry point cites the reference interface it
+ * replaces (file:line into bliss-rs / `bliss-audio` 0.13.0); INTEGRATION.md shows the Rust
+ * `extern "C"` binding a bliss-rs maintainer would add.
+ *
+ * Input contract (same as Song::analyze, src/song/mod.rs:389-392): mono, 22 050 Hz, f32le PCM.
+ * Output: one row of 23 (FeaturesVersion::Version2) or 20 (Version1) f32 per song, in the reference's
+ * order [tempo, zcr, centroid mean/std, rolloff mean/std, flatness mean/std, loudness mean/std,
+ * chroma x13|x10] (src/song/mod.rs:493-498, 102-156).
+ *
+ * Threading: a context is used by one host thread at a time (create one context per worker thread, as
+ * bliss-rs creates one descriptor set per analyze call); different contexts are independent.
+ * The library has NO CPU fallback: every compute entry point fails with BLISSGPU_ERR_NO_DEVICE when no
+ * gfx950 device / HIP runtime is usable.
+ */
+#ifndef BLISSGPU_H
+#define BLISSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- return codes (whole-call) ---- */
+#define BLISSGPU_OK 0
+#define BLISSGPU_ERR_NO_DEVICE 1      /* no usable HIP device: there is no CPU path */
+#define BLISSGPU_ERR_INVALID 2        /* bad argument (NULL pointer, unknown features_version/metric, d > 64) */
+#define BLISSGPU_ERR_HIP 3            /* a HIP runtime call failed; see blissgpu_last_error() */
+#define BLISSGPU_ERR_OOM 4            /* workspace allocation failed */
+
+/* ---- per-song status, maps 1:1 onto BlissError (src/lib.rs:236-252) ---- */
+#define BLISSGPU_SONG_OK 0
+#define BLISSGPU_SONG_TOO_SHORT 1     /* AnalysisError("empty or too short song.") -- len < 8192 (src/song/mod.rs:417-430) */
+
+/* ---- FeaturesVersion (src/lib.rs:151-187) ---- */
+#define BLISSGPU_FEATURES_V1 1u       /* 20 features */
+#define BLISSGPU_FEATURES_V2 2u       /* 23 features (LATEST) */
+
+/* ---- distance metrics (src/playlist.rs:65-79, 129-142) ---- */
+#define BLISSGPU_METRIC_EUCLIDEAN 0
+#define BLISSGPU_METRIC_COSINE 1
+#define BLISSGPU_METRIC_MAHALANOBIS 2
+
+typedef struct blissgpu_ctx blissgpu_ctx;
+
+/* Context = device selection + constant tables (windows, twiddles, the 100 chroma filter banks of
+ * chroma_filter(), src/chroma.rs:197-267) + a grow-only HBM workspace + one HIP stream. */
+int blissgpu_ctx_create(int device, blissgpu_ctx **ctx);
+int blissgpu_ctx_destroy(blissgpu_ctx *ctx);
+/* Launch on a caller-owned stream (a hipStream_t passed as void*, e.g. torch's current stream);
+ * NULL restores the context's own stream. */
+int blissgpu_ctx_set_stream(blissgpu_ctx *ctx, void *hip_stream);
+void *blissgpu_ctx_get_stream(blissgpu_ctx *ctx);
+/* Upper bound for the scratch workspace in bytes (default 96 GiB); larger batches run in chunks. */
+int blissgpu_ctx_set_workspace_limit(blissgpu_ctx *ctx, uint64_t bytes);
+int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
+
+uint32_t blissgpu_feature_count(uint32_t features_version); /* FeaturesVersion::feature_count, src/lib.rs:181-186 */
+
+/* Replaces Song::analyze / Song::analyze_with_options (src/song/mod.rs:403-508) for ONE song in host
+ * memory.  Returns BLISSGPU_OK and writes feature_count floats, or BLISSGPU_OK with *status =
+ * BLISSGPU_SONG_TOO_SHORT (out filled with NaN).  status may be NULL.  Uses a process-wide default
+ * context on device 0. */
+int blissgpu_analyze(const float *pcm, uint64_t len, uint32_t features_version, float *out, int32_t *status);
+
+/* Bulk form: the compute half of Decoder::analyze_paths_with_options (src/song/decoder.rs:278-332) once the
+ * decoders have produced PCM.  pcm holds the songs back to back (song i = pcm[offsets[i] ..
+ * offsets[i] + lengths[i])); out is n_songs x feature_count row-major; status has one entry per
+ * song -- one bad song never aborts the batch (src/song/decoder.rs:313-325).  Host pointers. */
+int blissgpu_analyze_batch(const float *pcm, const uint64_t *offsets, const uint64_t *lengths, uint32_t n_songs,
+                           uint32_t features_version, float *out, int32_t *status);
+
+/* Device-resident form: d_pcm / d_out / d_status are HIP device pointers (d_status may be NULL),
+ * offsets / lengths stay on the host (they size the launch).  Asynchronous on the context's
+ * stream; call blissgpu_ctx_synchronize (or synchronise the stream) before reading d_out. */
+int blissgpu_analyze_batch_device(blissgpu_ctx *ctx, const float *d_pcm, const uint64_t *offsets,
+                                  const uint64_t *lengths, uint32_t n_songs, uint32_t features_version,
+                                  float *d_out, int32_t *d_status);
+
+/* Song::distance / Analysis::distance (src/song/mod.rs:364-370, 519-521) and the free functions
+ * euclidean_distance / cosine_distance / mahalanobis_distance (src/playlist.rs:65-79, 140-142) for one
+ * pair (host pointers; M is d x d row-major, required for MAHALANOBIS, ignored otherwise). */
+int blissgpu_distance(const float *a, const float *b, uint32_t d, int metric, const float *M, float *out);
+
+/* All-pairs form: out[i * m + j] = metric(A[i], B[j]).  A is n x d, B is m x d, row-major f32.  This
+ * is the batched equivalent of evaluating a DistanceMetric over every candidate
+ * (src/playlist.rs:24-59, 256-270).  Host pointers. */
+int blissgpu_pairwise(const float *A, uint64_t n, const float *B, uint64_t m, uint32_t d, int metric, const float *M,
+                      float *out);
+/* Device-resident form; ld_out is the row pitch of d_out in elements (>= m).  Asynchronous. */
+int blissgpu_pairwise_device(blissgpu_ctx *ctx, const float *d_A, uint64_t n, const float *d_B, uint64_t m,
+                             uint32_t d, int metric, const float *d_M, float *d_out, uint64_t ld_out);
+
+/* FeaturesVersion::feature_weights (src/lib.rs:168-173, 209-234): d x d row-major diagonal matrix. */
+int blissgpu_feature_weights(uint32_t features_version, float *M);
+
+/* ---- device memory helpers for hosts without their own HIP binding (Rust/C callers) ---- */
+int blissgpu_malloc(void **d_ptr, uint64_t bytes);
+int blissgpu_free(void *d_ptr);
+int blissgpu_memcpy_h2d(blissgpu_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+int blissgpu_memcpy_d2h(blissgpu_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+
+/* ---- benchmark input: synthetic white noise written straight into HBM.  Song i of the call gets
+ * uniform [-0.5, 0.5) samples from Philox4x32-10 with key (0x5EED0000 + first_song_index + i, 0) and
+ * counter = sample_index / 4 (bit-identical to the oracle's generator).  No reference counterpart. */
+int blissgpu_synth_white_noise_device(blissgpu_ctx *ctx, float *d_pcm, const uint64_t *offsets,
+                                      const uint64_t *lengths, uint32_t n_songs, uint32_t first_song_index);
+
+/* ---- per-kernel timing with HIP events on the context's stream (for bench.py's roofline) ---- */
+int blissgpu_profile_enable(blissgpu_ctx *ctx, int enable);
+int blissgpu_profile_reset(blissgpu_ctx *ctx);
+int blissgpu_profile_kernel_count(void);
+const char *blissgpu_profile_kernel_name(int kernel);
+/* total_ms / launches accumulated since the last reset (synchronises the stream) */
+int blissgpu_profile_get(blissgpu_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
+
+/* ---- debug taps used by the parity tests: per-song tuning estimate of the last batch ----
+ * tuning[i] = estimate_tuning's value for song i of the last analyze_batch_device call on ctx
+ * (src/chroma.rs:361-391); n_bpms[i] = number of beats BPMDesc recorded (src/temporal.rs:50-58). */
+int blissgpu_debug_last_tuning(blissgpu_ctx *ctx, double *tuning, uint32_t *n_bpms, uint32_t n_songs);
+
+/* Intermediate series of song `song` of the LAST chunk run on ctx (per-stage parity tests).  Copies at
+ * most max_elems 4-byte elements to dst, reports the available count in *n_elems. */
+#define BLISSGPU_DEBUG_CENTROID 0      /* f32[n_t]  per-frame spectral centroid in Hz (src/timbral.rs:159-173) */
+#define BLISSGPU_DEBUG_ROLLOFF 1       /* f32[n_t]  per-frame rolloff in Hz (:175-194) */
+#define BLISSGPU_DEBUG_FLATNESS 2      /* f32[n_t]  per-frame flatness (:196-208) */
+#define BLISSGPU_DEBUG_FLUX 3          /* f32[n_b]  SpecFlux onset values (src/aubio.rs:455-467) */
+#define BLISSGPU_DEBUG_THRESHOLDED 4   /* f32[n_b]  PeakPicker thresholded values (:757) */
+#define BLISSGPU_DEBUG_RUN_BPM 5       /* f32[runs] BeatTracking::get_bpm after each run (:1231-1239) */
+#define BLISSGPU_DEBUG_RUN_COUNT 6     /* u32[runs] beats BPMDesc recorded while that bpm was current */
+#define BLISSGPU_DEBUG_SPECTROGRAM 7   /* f32[n_c][4112] STFT magnitudes, 4097 valid per row (src/utils.rs:26-64) */
+#define BLISSGPU_DEBUG_ENERGY256 8     /* f32[ceil(n/256)] sum of squares per 256 samples */
+#define BLISSGPU_DEBUG_CROSSINGS256 9  /* u32[ceil(n/256)] zero crossings per 256 samples */
+#define BLISSGPU_DEBUG_PITCH_HIST 10   /* u32[100] pitch-residue histogram (peaks above the median's coarse bin) */
+int blissgpu_debug_fetch(blissgpu_ctx *ctx, int what, uint32_t song, void *dst, uint64_t max_elems, uint64_t *n_elems);
+
+const char *blissgpu_strerror(int code);
+const char *blissgpu_last_error(void); /* thread-local detail of the last failure */
+const char *blissgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLISSGPU_H */

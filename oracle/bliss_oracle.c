@@ -57,9 +57,37 @@ static void fft_free(bo_fft *p) {
     free(p);
 }
 
+/* Sensitivity switch (tests only): run the butterflies in f64 and round the result to f32 once.
+ * Not the reference's arithmetic (rustfft works in f32); it exists to measure how much each feature
+ * moves under FFT rounding alone, which bounds what GPU-vs-CPU parity can mean. */
+static int g_fft_double = 0;
+void bo_set_fft_double(int on) { g_fft_double = on; }
+
+static void fft_forward_f64(const bo_fft *p, float *re32, float *im32) {
+    const size_t n = p->n;
+    double *re = (double *)malloc(sizeof(double) * n), *im = (double *)malloc(sizeof(double) * n);
+    for (size_t i = 0; i < n; i++) { re[p->rev[i]] = re32[i]; im[p->rev[i]] = im32[i]; }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t half = len >> 1;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t j = 0; j < half; j++) {
+                const double a = -2.0 * M_PI * (double)j / (double)len;
+                const double wr = cos(a), wi = sin(a);
+                const double xr = re[i + j + half], xi = im[i + j + half];
+                const double vr = xr * wr - xi * wi, vi = xr * wi + xi * wr;
+                const double ur = re[i + j], ui = im[i + j];
+                re[i + j] = ur + vr; im[i + j] = ui + vi;
+                re[i + j + half] = ur - vr; im[i + j + half] = ui - vi;
+            }
+    }
+    for (size_t i = 0; i < n; i++) { re32[i] = (float)re[i]; im32[i] = (float)im[i]; }
+    free(re); free(im);
+}
+
 /* in-place forward FFT on separate re/im arrays */
 static void fft_forward(const bo_fft *p, float *re, float *im) {
     const size_t n = p->n;
+    if (g_fft_double) { fft_forward_f64(p, re, im); return; }
     for (size_t i = 0; i < n; i++) {
         size_t j = p->rev[i];
         if (j > i) {

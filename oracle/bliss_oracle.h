@@ -106,6 +106,9 @@ void bo_pairwise(const float *A, size_t n, const float *B, size_t m, size_t d, i
  * uniform [-0.5, 0.5), key = (0x5EED0000 + song_index, 0), counter = sample_index / 4 ---- */
 void bo_white_noise(uint32_t song_index, size_t n, float *out);
 
+/* tests only: evaluate every FFT in f64 (rounded to f32 once) to measure FFT-rounding sensitivity */
+void bo_set_fft_double(int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,7 @@ def lib():
             "bo_feature_weights": (None, [C.c_uint32, f32p]),
             "bo_pairwise": (None, [f32p, sz, f32p, sz, sz, C.c_int, f32p, f32p, C.c_uint32]),
             "bo_white_noise": (None, [C.c_uint32, sz, f32p]),
+            "bo_set_fft_double": (None, [C.c_int]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -252,7 +253,7 @@ class SpectralDesc:
         return tuple(np.ctypeslib.as_array(p, shape=(n,)).copy() for p in (pc, pr, pf))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib().bo_spectral_desc_free(self._h)
             self._h = None
 
@@ -305,7 +306,7 @@ class BPMDesc:
         return (np.ctypeslib.as_array(po, shape=(n,)).copy(), np.ctypeslib.as_array(pt, shape=(n,)).copy())
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib().bo_bpm_desc_free(self._h)
             self._h = None
 
@@ -388,3 +389,8 @@ def white_noise(song_index, n):
     out = np.empty(n, np.float32)
     lib().bo_white_noise(song_index, n, _p(out, C.c_float))
     return out
+
+
+def set_fft_double(on):
+    """tests only: FFTs evaluated in f64 then rounded -- measures sensitivity to FFT rounding"""
+    lib().bo_set_fft_double(int(bool(on)))
