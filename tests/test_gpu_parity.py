@@ -1,0 +1,363 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs, against the reference's golden vectors, and -- at BASELINE.json's full sizes -- through
+size-independent properties.
+
+Tolerances (features are normalised to [-1, 1]):
+  * integer work (zero crossings, statuses, pitch histogram bins, beat counts): exact
+  * distances: bit-exact (the kernel reproduces ndarray's summation order)
+  * the 22 non-tempo features: |gpu - oracle| <= FEATURE_TOL = 2e-5 (observed <= 5e-6); the only
+    difference between the two paths is f32 FFT rounding (radix-4 Stockham + real split on the GPU,
+    radix-2 c2c in the oracle, rustfft in the reference -- no two of them round alike).  Rolloff is a
+    per-frame integer bin, so one frame flipping by one bin moves its mean by 43.07 Hz / n_frames:
+    the rolloff entries get ROLLOFF_FLIPS such flips on top.
+  * tempo: the beat tracker is a chain of argmax / threshold decisions; a flipped decision is not an
+    error of degree.  Songs whose tempo differs by more than TEMPO_TOL = 1e-4 are COUNTED and reported;
+    the battery requires >= 90 % agreement (observed: 100 %).
+  * tuning (discrete, 0.01 semitone bins): must match for every song of the battery; a mismatch would
+    be reported, not hidden (white noise makes the histogram argmax a near-tie by construction).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+FEATURE_TOL = 2e-5
+TEMPO_TOL = 1e-4
+ROLLOFF_FLIPS = 4
+N3MIN = 3969000
+
+
+@pytest.fixture(scope="module")
+def bliss():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import bliss_rs_amd
+
+    return bliss_rs_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(bliss):
+    return bliss.Context(0)
+
+
+def _run(ctx, songs, version=2):
+    import torch
+
+    lens = [len(s) for s in songs]
+    offs = np.concatenate([[0], np.cumsum([(l + 63) // 64 * 64 for l in lens])[:-1]]).astype(np.uint64)
+    buf = np.zeros(int(offs[-1]) + lens[-1] + 64, np.float32)
+    for s, o in zip(songs, offs):
+        buf[int(o):int(o) + len(s)] = s
+    pcm = torch.from_numpy(buf).cuda()
+    out, status = ctx.analyze(pcm, offs, lens, version)
+    ctx.synchronize()
+    return out.cpu().numpy(), status.cpu().numpy()
+
+
+def _tol(n_samples, d):
+    tol = np.full(d, FEATURE_TOL)
+    tol[0] = TEMPO_TOL
+    n_t = (n_samples - 512) // 128 + 1
+    flip = 2.0 * (22050.0 / 512.0) / 11025.0 / n_t
+    tol[4] += ROLLOFF_FLIPS * flip                                   # mean rolloff
+    tol[5] += ROLLOFF_FLIPS * flip * np.sqrt(max(n_t, 1)) * 0.5      # its std moves ~ bin / sqrt(n)
+    return tol
+
+
+def battery(oracle):
+    rng = np.random.default_rng(7)
+    t = np.arange(20 * 22050) / 22050.0
+    chord = sum(np.sin(2 * np.pi * f * t) for f in (261.63, 329.63, 392.0)) * 0.2
+    songs = {
+        "noise_3min": oracle.white_noise(11, N3MIN),
+        "noise_47s_odd": oracle.white_noise(12, 47 * 22050 + 1234),
+        "noise_exact_hop_multiple": oracle.white_noise(13, 2205 * 300),       # last STFT window dropped
+        "min_len_8192": oracle.white_noise(14, 8192),
+        "len_8193": oracle.white_noise(15, 8193),
+        "silence": np.zeros(3 * 22050, np.float32),
+        "dc_offset": np.full(2 * 22050, 0.25, np.float32),
+        "click_60bpm": np.tile(np.concatenate([np.zeros(22000, np.float32), np.ones(100, np.float32)]), 40),
+        "click_192bpm": np.tile(np.concatenate([np.zeros(6989, np.float32), np.ones(20, np.float32)]), 120),
+        "c_major_chord": chord.astype(np.float32),
+        "sweep": np.sin(2 * np.pi * (100 + 2000 * t) * t).astype(np.float32) * 0.5,
+        "square_wave": np.tile(np.array([-1.0] * 25 + [1.0] * 25, np.float32), 4000),
+        "quiet_noise": (rng.standard_normal(5 * 22050) * 1e-4).astype(np.float32),
+        "loud_clipped": np.clip(rng.standard_normal(6 * 22050), -1, 1).astype(np.float32),
+        "silence_then_noise": np.concatenate([np.zeros(4 * 22050, np.float32), oracle.white_noise(16, 8 * 22050)]),
+    }
+    return songs
+
+
+# ---------------------------------------------------------------------------------------------
+# golden vectors of the reference (src/song/mod.rs:553-633), at the reference's own tolerance
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("version,key", [(2, "analysis_v2_s16_mono_22_5kHz"), (1, "analysis_v1_s16_mono_22_5kHz")])
+def test_golden_song_matches_reference_literals(bliss, golden_pcm, literals, version, key):
+    analysis = bliss.Song.analyze_with_options(golden_pcm, bliss.AnalysisOptions(bliss.FeaturesVersion(version)))
+    exp = np.array(literals[key]["values"], np.float32)
+    got = analysis.as_arr1()
+    assert got.shape == exp.shape
+    assert np.abs(got - exp).max() < literals[key]["tol"], (got - exp)
+
+
+def test_golden_song_matches_oracle(ctx, oracle, golden_pcm):
+    for version in (2, 1):
+        got, status = _run(ctx, [golden_pcm], version)
+        ref = oracle.song_analyze(golden_pcm, version)
+        assert status.tolist() == [0]
+        assert (np.abs(got[0] - ref) <= _tol(len(golden_pcm), len(ref))).all(), np.abs(got[0] - ref)
+    tuning, n_bpms = ctx.last_tuning(1)
+    assert abs(tuning[0] + 0.05) < 1e-12          # estimate_tuning of the golden song (src/chroma.rs:655-665)
+    assert n_bpms[0] == 23                        # beats BPMDesc records on it
+
+
+# ---------------------------------------------------------------------------------------------
+# battery vs oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("version", [2, 1])
+def test_battery_vs_oracle(ctx, oracle, version):
+    songs = battery(oracle)
+    names = list(songs)
+    got, status = _run(ctx, [songs[k] for k in names], version)
+    tuning, n_bpms = ctx.last_tuning(len(names))
+    assert (status == 0).all()
+    tempo_mismatch, report = [], []
+    for i, k in enumerate(names):
+        ref = oracle.song_analyze(songs[k], version)
+        _, otuning = oracle.chroma_desc(songs[k])
+        err = np.abs(got[i] - ref)
+        tol = _tol(len(songs[k]), len(ref))
+        report.append(f"{k:26s} max|err| non-tempo {err[1:].max():.2e} tempo {err[0]:.2e} tuning {tuning[i]:+.2f}/{otuning:+.2f}")
+        assert abs(tuning[i] - otuning) < 1e-12, f"{k}: tuning gpu {tuning[i]} oracle {otuning}"
+        assert (err[1:] <= tol[1:]).all(), f"{k}: {err}"
+        if err[0] > tol[0]:
+            tempo_mismatch.append((k, float(got[i][0]), float(ref[0])))
+        assert n_bpms[i] == len(oracle.BPMDesc().run(songs[k]).bpms()) or err[0] > tol[0]
+    print("\n".join(report))
+    print("tempo mismatches:", tempo_mismatch)
+    assert len(tempo_mismatch) <= len(names) // 10, tempo_mismatch
+
+
+def test_stage_taps_vs_oracle(ctx, oracle, golden_pcm):
+    """Every intermediate series against the oracle's streaming descriptors."""
+    songs = [golden_pcm, oracle.white_noise(21, 30 * 22050 + 100)]
+    _run(ctx, songs, 2)
+    for i, x in enumerate(songs):
+        sd = oracle.SpectralDesc().run(x)
+        c, r, f = sd.series()
+        gc, gr, gf = (ctx.debug_fetch(k, i) for k in ("centroid", "rolloff", "flatness"))
+        assert len(gc) == len(c) == (len(x) - 512) // 128 + 1
+        assert np.abs(gc - c).max() < 2e-2                  # Hz, on values up to 11025
+        assert (np.abs(gr - r) > 1e-3).sum() <= 4           # integer bins x 43.07 Hz: a handful may flip by one
+        assert np.abs(gf - f).max() < 5e-6
+        bd = oracle.BPMDesc().run(x)
+        onset, thr = bd.series()
+        gflux, gthr = ctx.debug_fetch("flux", i), ctx.debug_fetch("thresholded", i)
+        assert len(gflux) == len(onset) == (len(x) - 512) // 256 + 1
+        assert np.abs(gflux - onset).max() <= 2e-6 * max(1.0, np.abs(onset).max())
+        assert np.abs(gthr - thr).max() <= 2e-6 * max(1.0, np.abs(onset).max())
+        # beat-tracker runs: same bpm sequence and beat counts
+        bpms = bd.bpms()
+        rb, rc = ctx.debug_fetch("run_bpm", i), ctx.debug_fetch("run_count", i)
+        assert int(rc.sum()) == len(bpms)
+        assert np.allclose(np.repeat(rb, rc), bpms, rtol=2e-5)
+        # STFT magnitudes and exact integer work
+        spec = oracle.stft(x, 8192, 2205)                   # [4097, frames]
+        gspec = ctx.debug_fetch("spectrogram", i)           # [frames, 4097]
+        assert gspec.shape == spec.T.shape
+        assert np.abs(gspec - spec.T).max() <= 3e-6 * spec.max()
+        zc = ctx.debug_fetch("crossings256", i)
+        assert int(zc.sum()) == oracle.number_crossings(x)  # exact
+        e = ctx.debug_fetch("energy256", i)
+        ref_e = np.add.reduceat(x.astype(np.float64) ** 2, np.arange(0, len(x), 256))
+        assert np.allclose(e, ref_e, rtol=1e-5, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# errors, ragged batches, independence, determinism
+# ---------------------------------------------------------------------------------------------
+def test_too_short_and_mixed_batch(bliss, ctx, oracle):
+    # src/song/mod.rs:539-551
+    for x in (np.zeros(1, np.float32), np.zeros(0, np.float32), np.zeros(8191, np.float32)):
+        with pytest.raises(bliss.AnalysisError, match="empty or too short song."):
+            bliss.Song.analyze(x)
+    songs = [oracle.white_noise(1, 9000), np.zeros(100, np.float32), oracle.white_noise(2, 30000),
+             np.zeros(0, np.float32), oracle.white_noise(3, 8192)]
+    res = bliss.analyze_batch(songs)
+    assert [isinstance(r, bliss.AnalysisError) for r in res] == [False, True, False, True, False]
+    assert res[1] == bliss.AnalysisError("empty or too short song.")
+    got, status = _run(ctx, [s if len(s) else np.zeros(1, np.float32) for s in songs])
+    assert status.tolist() == [0, 1, 0, 1, 0]
+    assert np.isnan(got[1]).all() and np.isnan(got[3]).all()
+    for i in (0, 2, 4):
+        assert np.array_equal(got[i], res[i].as_arr1())     # host-buffer and device-resident entry points agree
+        ref = oracle.song_analyze(songs[i])
+        assert (np.abs(got[i][1:] - ref[1:]) <= _tol(len(songs[i]), 23)[1:]).all()
+
+
+def test_batch_composition_and_order_do_not_matter(ctx, oracle):
+    songs = [oracle.white_noise(40 + i, n) for i, n in enumerate((50000, 200001, 8192, 123457, 90000))]
+    a, _ = _run(ctx, songs)
+    perm = [3, 0, 4, 2, 1]
+    b, _ = _run(ctx, [songs[p] for p in perm])
+    for j, p in enumerate(perm):
+        assert np.array_equal(a[p], b[j])                    # bit-identical
+    c, _ = _run(ctx, [songs[1]])
+    assert np.array_equal(c[0], a[1])
+    a2, _ = _run(ctx, songs)
+    assert np.array_equal(a, a2)                             # deterministic run to run
+
+
+def test_workspace_chunking(bliss, oracle):
+    """A tiny workspace limit forces several chunks; results must not change."""
+    songs = [oracle.white_noise(60 + i, 40000 + 1000 * i) for i in range(6)]
+    c1 = bliss.Context(0)
+    ref, _ = _run(c1, songs)
+    c2 = bliss.Context(0)
+    c2.set_workspace_limit(64 << 20)
+    got, status = _run(c2, songs)
+    assert np.array_equal(ref, got) and (status == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size (BASELINE configs[1] song size) properties
+# ---------------------------------------------------------------------------------------------
+def test_full_size_properties(ctx, oracle):
+    """3-minute songs generated in HBM: (a) the device generator is bit-identical to the oracle's, (b) a
+    sample of songs matches the oracle, (c) ZCR is exact, (d) scaling the PCM by 1/2 (exact in binary
+    floating point) leaves every feature bit-identical except the two loudness entries, which move by
+    exactly 10*log10(1/4) dB."""
+    import torch
+
+    n, N = 24, N3MIN
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(N)
+    lens = np.full(n, N, np.uint64)
+    pcm = torch.empty(n * N, dtype=torch.float32, device="cuda")
+    ctx.synth_white_noise(pcm, offs, lens, first_song_index=100)
+    out, status = ctx.analyze(pcm, offs, lens, 2)
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all() and np.isfinite(got).all()
+    tempo_bad = 0
+    for i in (0, 7, 23):
+        x = oracle.white_noise(100 + i, N)
+        assert np.array_equal(pcm[i * N:(i + 1) * N].cpu().numpy(), x)
+        ref = oracle.song_analyze(x)
+        err = np.abs(got[i] - ref)
+        assert (err[1:] <= _tol(N, 23)[1:]).all(), err
+        tempo_bad += err[0] > TEMPO_TOL
+        assert got[i][1] == np.float32(2.0 * np.float32(oracle.number_crossings(x)) / np.float32(N) - 1.0)
+    assert tempo_bad == 0
+    half = pcm * 0.5
+    out2, _ = ctx.analyze(half, offs, lens, 2)
+    ctx.synchronize()
+    got2 = out2.cpu().numpy()
+    keep = [i for i in range(23) if i not in (8, 9)]
+    assert np.array_equal(got[:, keep], got2[:, keep])
+    shift = 2.0 * (10.0 * np.log10(0.25)) / 90.0
+    assert np.abs((got2[:, 8:10] - got[:, 8:10]) - shift).max() < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# distances
+# ---------------------------------------------------------------------------------------------
+def test_distance_literals(bliss, literals):
+    # src/playlist.rs:1008-1024, 1081-1110 ; src/lib.rs:272-291 ; src/song/mod.rs:772-807 -- assert_eq on f32
+    lit = literals["distances"]
+    P = bliss.playlist
+    a = np.ones(20, np.float32)
+    a[19] = 0
+    b = np.zeros(20, np.float32)
+    b[16] = 1
+    assert np.float32(P.euclidean_distance(a, b)) == np.float32(lit["euclidean"]["value"])
+    assert np.float32(P.cosine_distance(a, b)) == np.float32(lit["cosine"]["value"])
+    h = np.full(20, 0.5, np.float32)
+    assert P.euclidean_distance(h, h) == 0.0 and P.cosine_distance(h, h) == 0.0
+    b2 = b.copy()
+    b2[0] = 1
+    m = np.zeros((20, 20), np.float32)
+    m[0, 0] = m[1, 1] = 1
+    assert P.mahalanobis_distance_builder(m)(a, b2) == 1.0
+    V1, V2 = bliss.FeaturesVersion.Version1, bliss.FeaturesVersion.Version2
+    assert np.float32(V1.distance_metric()(np.zeros(20), np.ones(20))) == np.float32(4.47213595)
+    assert np.float32(V2.distance_metric()(np.zeros(23), np.ones(23))) == np.float32(3.4999998)
+    first = bliss.Analysis(np.zeros(20), V1)
+    second = bliss.Analysis(np.ones(20), V1)
+    assert np.float32(first.distance(second)) == np.float32(4.472136)
+    s1, s2 = bliss.Song(analysis=first), bliss.Song(analysis=second)
+    assert np.float32(s1.distance(s2)) == np.float32(4.472136)
+    with pytest.raises(RuntimeError, match="Mismatched features version"):
+        first.distance(bliss.Analysis(np.zeros(23), V2))
+
+
+@pytest.mark.parametrize("d", [23, 20, 7, 33])
+def test_pairwise_bit_exact_vs_oracle(bliss, oracle, d):
+    rng = np.random.default_rng(d)
+    A = rng.uniform(-1, 1, (301, d)).astype(np.float32)
+    B = rng.uniform(-1, 1, (517, d)).astype(np.float32)
+    R = rng.uniform(-1, 1, (d, d)).astype(np.float32)
+    psd = (R @ R.T).astype(np.float32)
+    diag = np.diag(rng.uniform(0, 1, d).astype(np.float32)).astype(np.float32)
+    for metric, m in (("euclidean", None), ("cosine", None), ("mahalanobis", diag), ("mahalanobis", psd)):
+        got = bliss.playlist.pairwise_distances(A, B, metric, m)
+        ref = oracle.pairwise(A, B, metric, m)
+        assert np.array_equal(got, ref, equal_nan=True), (metric, np.nanmax(np.abs(got - ref)))
+    # cosine with a zero vector is NaN in the reference too (no guard, src/playlist.rs:76-79)
+    Z = np.zeros((1, d), np.float32)
+    assert np.isnan(bliss.playlist.pairwise_distances(Z, B[:4], "cosine")).all()
+
+
+def test_pairwise_full_size_properties(ctx, oracle):
+    """BASELINE configs[3]: 100 000 x 100 000 euclidean matrix on one GPU (40 GB): zero diagonal, exact
+    symmetry and 10^5 random entries against the oracle, all bit-exact."""
+    import torch
+
+    n, d = 100000, 23
+    g = torch.Generator(device="cuda").manual_seed(99)
+    A = torch.rand((n, d), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+    D = ctx.pairwise(A, A, "euclidean")
+    torch.cuda.synchronize()
+    assert float(torch.diagonal(D).abs().max()) == 0.0
+    rng = np.random.default_rng(5)
+    ii = torch.from_numpy(rng.integers(0, n, 100000)).cuda()
+    jj = torch.from_numpy(rng.integers(0, n, 100000)).cuda()
+    assert torch.equal(D[ii, jj], D[jj, ii])
+    Ah = A.cpu().numpy()
+    got = D[ii, jj].cpu().numpy()
+    ih, jh = ii.cpu().numpy(), jj.cpu().numpy()
+    ref = np.array([oracle.euclidean_distance(Ah[i], Ah[j]) for i, j in zip(ih[:20000], jh[:20000])], np.float32)
+    assert np.array_equal(got[:20000], ref)
+    assert torch.isfinite(D[::997, ::991]).all()
+    del D
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference-shaped host API on the GPU
+# ---------------------------------------------------------------------------------------------
+def test_decoder_trait_bulk_path(bliss, oracle, tmp_path, golden_pcm):
+    good = tmp_path / "golden.npy"
+    np.save(good, load_golden("s16_mono_22_5kHz.pcm_s16.npy"))
+    short = tmp_path / "short.npy"
+    np.save(short, np.zeros(100, np.float32))
+    missing = str(tmp_path / "nope.npy")
+    D = bliss.RawPcmDecoder
+    song = D.song_from_path(str(good))
+    assert song.path == str(good) and song.features_version == bliss.FeaturesVersion.LATEST
+    assert abs(song.duration - len(golden_pcm) / 22050) < 1e-6
+    ref = oracle.song_analyze(golden_pcm)
+    assert np.abs(song.analysis.as_arr1() - ref).max() < 1e-4
+    assert song.analysis[bliss.AnalysisIndex.Zcr] == pytest.approx(-0.849141, abs=1e-6)
+    res = dict(D.analyze_paths([str(good), str(short), missing]))
+    assert isinstance(res[str(good)], bliss.Song) and res[str(good)].analysis == song.analysis
+    assert res[str(short)] == bliss.AnalysisError("empty or too short song.")
+    assert isinstance(res[missing], bliss.DecodingError)
+    v1 = D.song_from_path_with_options(str(good), bliss.AnalysisOptions(bliss.FeaturesVersion.Version1))
+    assert len(v1.analysis.as_vec()) == 20
+    with pytest.raises(RuntimeError, match="incompatible indexes"):
+        v1.analysis[bliss.AnalysisIndex.Tempo]

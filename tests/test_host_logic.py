@@ -1,0 +1,175 @@
+"""CPU-only tests: host logic of the reference-shaped API, C-ABI export check, sharding, and the
+world_size-2 gloo path of the feature all-gather."""
+import ctypes
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def bliss():
+    import bliss_rs_amd
+
+    return bliss_rs_amd
+
+
+def test_c_abi_exports_every_declared_symbol(bliss):
+    so = bliss.LIB_PATH
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+
+        g.build()
+    lib = ctypes.CDLL(so)
+    header = open(os.path.join(ROOT, "include", "blissgpu.h")).read()
+    declared = sorted(set(re.findall(r"\b(blissgpu_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/blissgpu.h but not exported"
+    from bliss_rs_amd import _ffi
+
+    assert sorted(_ffi.SIGNATURES) == declared
+    # no compute without a GPU: version / strerror / feature_count / weights are host-only
+    lib.blissgpu_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.blissgpu_version()
+    lib.blissgpu_strerror.restype = ctypes.c_char_p
+    assert b"no CPU path" in lib.blissgpu_strerror(1)
+    assert lib.blissgpu_feature_count(2) == 23 and lib.blissgpu_feature_count(1) == 20 and lib.blissgpu_feature_count(3) == 0
+
+
+def test_no_cpu_fallback_without_device(bliss):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(bliss.BlissGpuError) as e:
+        bliss.Song.analyze(np.zeros(10000, np.float32))
+    assert e.value.code == 1  # BLISSGPU_ERR_NO_DEVICE
+    with pytest.raises(RuntimeError):
+        bliss.Context(0)
+
+
+def test_features_version_and_weights(bliss):
+    FV = bliss.FeaturesVersion
+    assert FV.LATEST == FV.Version2 and bliss.NUMBER_FEATURES == 23
+    assert FV.Version1.feature_count() == 20 and FV.Version2.feature_count() == 23
+    assert FV.try_from(1) == FV.Version1 and FV.try_from(2) == FV.Version2
+    with pytest.raises(bliss.ProviderError, match=r"This features' version \(3\) does not exist"):
+        FV.try_from(3)
+    # src/lib.rs:261-270 test_dimensions_weights ; :209-234 VERSION2_WEIGHTS
+    assert FV.Version1.feature_weights().shape == (20, 20) and FV.Version2.feature_weights().shape == (23, 23)
+    w = np.diag(FV.Version2.feature_weights())
+    assert w[0] == np.float32(0.25) and (w[1:10] == 1).all() and (w[10:] == np.float32(3.0 / 13.0)).all()
+    assert np.array_equal(FV.Version1.feature_weights(), np.eye(20, dtype=np.float32))
+
+
+def test_analysis_container(bliss):
+    A, FV = bliss.Analysis, bliss.FeaturesVersion
+    with pytest.raises(bliss.ProviderError, match="Feature count 3 does not match the expected version feature count 23"):
+        A([0.0, 1.0, 2.0], FV.LATEST)
+    a = A(np.arange(23) / 10.0, FV.Version2)
+    assert a[bliss.AnalysisIndex.Tempo] == 0.0 and a[bliss.AnalysisIndex.Chroma13] == pytest.approx(2.2)
+    assert len(list(bliss.AnalysisIndex)) == 23 and len(list(bliss.AnalysisIndexv1)) == 20
+    with pytest.raises(RuntimeError, match="incompatible indexes"):
+        a[bliss.AnalysisIndexv1.Tempo]
+    assert a == A(a.as_vec(), FV.Version2) and a != A(np.zeros(23), FV.Version2)
+    assert a.as_arr1().dtype == np.float32 and "Version 2" in repr(a)
+    assert str(bliss.AnalysisError("empty or too short song.")) == \
+        "error happened while analyzing file - empty or too short song."
+    opts = bliss.AnalysisOptions()
+    assert opts.features_version == FV.LATEST and opts.number_cores >= 1
+
+
+def test_decoder_host_side(bliss, tmp_path):
+    class Broken(bliss.Decoder):
+        @classmethod
+        def decode(cls, path):
+            raise bliss.DecodingError(f"while opening format for file '{path}'")
+
+    out = list(Broken.analyze_paths(["a.flac", "b.flac"]))
+    assert [p for p, _ in out] == ["a.flac", "b.flac"]
+    assert all(isinstance(r, bliss.DecodingError) for _, r in out)
+    with pytest.raises(bliss.DecodingError):
+        bliss.RawPcmDecoder.decode(str(tmp_path / "missing.wav"))
+    p = tmp_path / "stereo.npy"
+    np.save(p, np.zeros((10, 2), np.float32))
+    with pytest.raises(bliss.DecodingError):
+        bliss.RawPcmDecoder.decode(str(p))
+    q = tmp_path / "s16.npy"
+    np.save(q, np.array([16384, -32768], np.int16))
+    assert bliss.RawPcmDecoder.decode(str(q)).sample_array.tolist() == [0.5, -1.0]
+
+
+def test_flac_test_tool(golden_pcm):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    from flac_decode import adler32_f32le
+
+    assert adler32_f32le(golden_pcm) == 0x5E01930B
+
+
+def test_shard_songs_balances_samples(bliss):
+    from bliss_rs_amd.shard import row_block, shard_songs
+
+    rng = np.random.default_rng(0)
+    lengths = rng.integers(661500, 13230000, 50000)  # BASELINE configs[4]: 30 s - 10 min
+    shards = shard_songs(lengths, 8)
+    allidx = np.sort(np.concatenate(shards))
+    assert np.array_equal(allidx, np.arange(len(lengths)))
+    loads = np.array([lengths[s].sum() for s in shards])
+    assert loads.max() / loads.min() < 1.0005
+    eq = shard_songs(np.full(10000, 3969000), 8)   # configs[2]: 10 000 equal songs -> 1250 each
+    assert [len(s) for s in eq] == [1250] * 8
+    blocks = [row_block(100003, r, 8) for r in range(8)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == 100003 and all(blocks[i][1] == blocks[i + 1][0] for i in range(7))
+
+
+_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path[:0] = [{root!r}, os.path.join({root!r}, "oracle")]
+import torch, torch.distributed as dist
+import bliss_rs_amd
+from bliss_rs_amd.shard import shard_songs, all_gather_features, row_block
+import oracle as O
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+lengths = [9000, 30000, 8192, 12000, 20000]
+mine = shard_songs(lengths, world)[rank]
+# the per-rank analysis is stood in for by the CPU oracle (the sharding + collective is what is under test)
+rows = np.stack([O.song_analyze(O.white_noise(int(i), lengths[int(i)])) for i in mine])
+full = all_gather_features(torch.from_numpy(rows), mine, len(lengths))
+ref = np.stack([O.song_analyze(O.white_noise(i, n)) for i, n in enumerate(lengths)])
+assert np.array_equal(full.numpy(), ref), "gathered matrix differs"
+lo, hi = row_block(len(lengths), rank, world)
+D = O.pairwise(ref[lo:hi], ref, "euclidean")
+parts = [None] * world
+dist.all_gather_object(parts, (lo, hi, D))
+whole = np.concatenate([p[2] for p in sorted(parts)], axis=0)
+assert np.array_equal(whole, O.pairwise(ref, ref, "euclidean"))
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_rank_gloo_shard_and_all_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {rank} ok" in o
