@@ -1,0 +1,215 @@
+// bliss_audio.hpp -- C++17 host-side mirror of the bliss-rs interface for the analysis hot path,
+// implemented on top of the C ABI in include/blissgpu.h (header-only; link with -lblissgpu).
+//
+// The reference is a Rust crate and this image has no Rust toolchain, so this header is the compiled
+// host layer that is tested here; the Rust binding a bliss-rs maintainer would add is in
+// INTEGRATION.md.  Names, argument meaning and error behaviour follow the reference:
+//
+//   bliss::Song::analyze / analyze_with_options      src/song/mod.rs:403-508
+//   bliss::Analysis, AnalysisIndex, FeaturesVersion  src/song/mod.rs:102-371, src/lib.rs:151-187
+//   bliss::BlissError {Decoding,Analysis,Provider}   src/lib.rs:236-252
+//   bliss::Decoder (decode / song_from_path / analyze_paths)   src/song/decoder.rs:115-333
+//   bliss::euclidean_distance / cosine_distance / mahalanobis_distance   src/playlist.rs:65-142
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "../../include/blissgpu.h"
+
+namespace bliss {
+
+constexpr uint32_t SAMPLE_RATE = 22050;  // src/lib.rs:140
+constexpr uint16_t CHANNELS = 1;         // src/lib.rs:137
+
+// ---- BlissError (src/lib.rs:236-252): value-returned on the analysis path, thrown here ----
+struct BlissError : std::runtime_error {
+    enum class Kind { DecodingError, AnalysisError, ProviderError } kind;
+    std::string message;
+    BlissError(Kind k, std::string m) : std::runtime_error(prefix(k) + m), kind(k), message(std::move(m)) {}
+    static std::string prefix(Kind k) {
+        switch (k) {
+            case Kind::DecodingError: return "error happened while decoding file - ";
+            case Kind::AnalysisError: return "error happened while analyzing file - ";
+            default: return "error happened with the music library provider - ";
+        }
+    }
+    bool operator==(const BlissError& o) const { return kind == o.kind && message == o.message; }
+};
+inline BlissError AnalysisError(std::string m) { return BlissError(BlissError::Kind::AnalysisError, std::move(m)); }
+inline BlissError DecodingError(std::string m) { return BlissError(BlissError::Kind::DecodingError, std::move(m)); }
+inline BlissError ProviderError(std::string m) { return BlissError(BlissError::Kind::ProviderError, std::move(m)); }
+
+// a failure of the GPU library itself (no device, HIP error): not a BlissError, there is no CPU path
+struct GpuError : std::runtime_error {
+    int code;
+    GpuError(int c) : std::runtime_error(std::string("blissgpu: ") + blissgpu_strerror(c) + " (" + blissgpu_last_error() + ")"), code(c) {}
+};
+inline void check(int rc) { if (rc != BLISSGPU_OK) throw GpuError(rc); }
+
+// ---- FeaturesVersion (src/lib.rs:151-187) ----
+enum class FeaturesVersion : uint16_t { Version1 = 1, Version2 = 2 };
+constexpr FeaturesVersion LATEST = FeaturesVersion::Version2;
+constexpr size_t feature_count(FeaturesVersion v) { return v == FeaturesVersion::Version2 ? 23 : 20; }
+constexpr size_t NUMBER_FEATURES = feature_count(LATEST);  // src/song/mod.rs:222
+inline FeaturesVersion features_version_try_from(uint16_t v) {
+    if (v == 1 || v == 2) return static_cast<FeaturesVersion>(v);
+    throw ProviderError("This features' version (" + std::to_string(v) + ") does not exist");
+}
+inline std::vector<float> feature_weights(FeaturesVersion v) {  // row-major d x d
+    std::vector<float> m(feature_count(v) * feature_count(v));
+    check(blissgpu_feature_weights(static_cast<uint32_t>(v), m.data()));
+    return m;
+}
+
+// ---- AnalysisIndex (src/song/mod.rs:102-156) ----
+enum class AnalysisIndex : size_t {
+    Tempo, Zcr, MeanSpectralCentroid, StdDeviationSpectralCentroid, MeanSpectralRolloff, StdDeviationSpectralRolloff,
+    MeanSpectralFlatness, StdDeviationSpectralFlatness, MeanLoudness, StdDeviationLoudness,
+    Chroma1, Chroma2, Chroma3, Chroma4, Chroma5, Chroma6, Chroma7, Chroma8, Chroma9, Chroma10, Chroma11, Chroma12, Chroma13
+};
+
+struct AnalysisOptions {  // src/song/mod.rs:248-269
+    FeaturesVersion features_version = LATEST;
+    size_t number_cores = 1;  // kept for interface parity; the batch is scheduled on the GPU
+};
+
+// ---- distances (src/playlist.rs:65-79, 129-142) ----
+inline float distance(const std::vector<float>& a, const std::vector<float>& b, int metric, const float* m = nullptr) {
+    if (a.size() != b.size()) throw std::invalid_argument("vectors must have the same length");
+    float out = 0.0f;
+    check(blissgpu_distance(a.data(), b.data(), static_cast<uint32_t>(a.size()), metric, m, &out));
+    return out;
+}
+inline float euclidean_distance(const std::vector<float>& a, const std::vector<float>& b) { return distance(a, b, BLISSGPU_METRIC_EUCLIDEAN); }
+inline float cosine_distance(const std::vector<float>& a, const std::vector<float>& b) { return distance(a, b, BLISSGPU_METRIC_COSINE); }
+inline float mahalanobis_distance(const std::vector<float>& a, const std::vector<float>& b, const std::vector<float>& m) {
+    return distance(a, b, BLISSGPU_METRIC_MAHALANOBIS, m.data());
+}
+using DistanceFn = std::function<float(const std::vector<float>&, const std::vector<float>&)>;
+inline DistanceFn mahalanobis_distance_builder(std::vector<float> m) {
+    return [m = std::move(m)](const std::vector<float>& a, const std::vector<float>& b) { return mahalanobis_distance(a, b, m); };
+}
+inline DistanceFn distance_metric(FeaturesVersion v) { return mahalanobis_distance_builder(feature_weights(v)); }  // src/lib.rs:176-178
+
+// ---- Analysis (src/song/mod.rs:238-371) ----
+class Analysis {
+  public:
+    std::vector<float> internal_analysis;
+    FeaturesVersion features_version = LATEST;
+    Analysis() = default;
+    Analysis(std::vector<float> analysis, FeaturesVersion v) : internal_analysis(std::move(analysis)), features_version(v) {
+        if (internal_analysis.size() != feature_count(v))
+            throw ProviderError("Feature count " + std::to_string(internal_analysis.size()) +
+                                " does not match the expected version feature count " + std::to_string(feature_count(v)));
+    }
+    const std::vector<float>& as_vec() const { return internal_analysis; }
+    float operator[](AnalysisIndex i) const {
+        if (features_version != LATEST) throw std::logic_error("Tried to index features with incompatible indexes");
+        return internal_analysis[static_cast<size_t>(i)];
+    }
+    bool operator==(const Analysis& o) const { return features_version == o.features_version && internal_analysis == o.internal_analysis; }
+    // default distance for the FeaturesVersion; the reference panics on mismatched versions (:364-370)
+    float distance(const Analysis& other) const {
+        if (features_version != other.features_version) throw std::logic_error("Mismatched features version between two songs or analysis");
+        return distance_metric(features_version)(internal_analysis, other.internal_analysis);
+    }
+};
+
+template <typename T>
+using BlissResult = std::variant<T, BlissError>;
+
+// Bulk Song::analyze_with_options over songs already decoded to mono 22 050 Hz f32 (one GPU batch).
+inline std::vector<BlissResult<Analysis>> analyze_batch(const std::vector<std::vector<float>>& songs, const AnalysisOptions& opt = {}) {
+    const uint32_t n = static_cast<uint32_t>(songs.size());
+    const size_t d = feature_count(opt.features_version);
+    std::vector<uint64_t> off(n), len(n);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) { off[i] = total; len[i] = songs[i].size(); total += len[i]; }
+    std::vector<float> pcm(total ? total : 1);
+    for (uint32_t i = 0; i < n; i++) std::copy(songs[i].begin(), songs[i].end(), pcm.begin() + off[i]);
+    std::vector<float> out(n * d);
+    std::vector<int32_t> status(n);
+    if (n) check(blissgpu_analyze_batch(pcm.data(), off.data(), len.data(), n, static_cast<uint32_t>(opt.features_version), out.data(), status.data()));
+    std::vector<BlissResult<Analysis>> res;
+    res.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (status[i] == BLISSGPU_SONG_OK) res.emplace_back(Analysis(std::vector<float>(out.begin() + i * d, out.begin() + (i + 1) * d), opt.features_version));
+        else if (status[i] == BLISSGPU_SONG_TOO_SHORT) res.emplace_back(AnalysisError("empty or too short song."));
+        else res.emplace_back(AnalysisError("analysis failed with status " + std::to_string(status[i])));
+    }
+    return res;
+}
+
+// ---- Song (src/song/mod.rs:45-76, 373-522) ----
+struct Song {
+    std::string path;
+    std::optional<std::string> artist, title, album, album_artist, genre;
+    std::optional<int32_t> track_number, disc_number;
+    double duration = 0.0;
+    Analysis analysis;
+    FeaturesVersion features_version = LATEST;
+
+    static Analysis analyze(const std::vector<float>& sample_array) { return analyze_with_options(sample_array, AnalysisOptions{}); }
+    static Analysis analyze_with_options(const std::vector<float>& sample_array, const AnalysisOptions& opt) {
+        auto r = analyze_batch({sample_array}, opt);
+        if (auto* e = std::get_if<BlissError>(&r[0])) throw *e;  // Err(AnalysisError("empty or too short song."))
+        return std::get<Analysis>(std::move(r[0]));
+    }
+    float distance(const Song& other) const { return analysis.distance(other.analysis); }
+};
+
+// ---- Decoder trait (src/song/decoder.rs:34-333) ----
+struct PreAnalyzedSong {
+    std::string path;
+    std::optional<std::string> artist, title, album, album_artist, genre;
+    std::optional<int32_t> track_number, disc_number;
+    double duration = 0.0;
+    std::vector<float> sample_array;
+    Song to_song(Analysis a, FeaturesVersion v) const {
+        Song s;
+        s.path = path; s.artist = artist; s.title = title; s.album = album; s.album_artist = album_artist; s.genre = genre;
+        s.track_number = track_number; s.disc_number = disc_number; s.duration = duration;
+        s.analysis = std::move(a); s.features_version = v;
+        return s;
+    }
+};
+
+class Decoder {
+  public:
+    virtual ~Decoder() = default;
+    // required method (src/song/decoder.rs:129): file -> mono 22 050 Hz f32 samples; throws BlissError
+    virtual PreAnalyzedSong decode(const std::string& path) const = 0;
+
+    Song song_from_path(const std::string& path) const { return song_from_path_with_options(path, AnalysisOptions{}); }
+    Song song_from_path_with_options(const std::string& path, const AnalysisOptions& opt) const {
+        PreAnalyzedSong pre = decode(path);
+        return pre.to_song(Song::analyze_with_options(pre.sample_array, opt), opt.features_version);
+    }
+    // (path, Result) pairs; a bad file never aborts the run (src/song/decoder.rs:313-325)
+    std::vector<std::pair<std::string, BlissResult<Song>>> analyze_paths(const std::vector<std::string>& paths, const AnalysisOptions& opt = {}) const {
+        std::vector<std::pair<std::string, BlissResult<Song>>> out;
+        std::vector<PreAnalyzedSong> pending;
+        for (const auto& p : paths) {
+            try { pending.push_back(decode(p)); }
+            catch (const BlissError& e) { out.emplace_back(p, e); }
+        }
+        std::vector<std::vector<float>> pcm;
+        pcm.reserve(pending.size());
+        for (auto& s : pending) pcm.push_back(s.sample_array);
+        auto res = analyze_batch(pcm, opt);
+        for (size_t i = 0; i < pending.size(); i++) {
+            if (auto* e = std::get_if<BlissError>(&res[i])) out.emplace_back(pending[i].path, *e);
+            else out.emplace_back(pending[i].path, pending[i].to_song(std::get<Analysis>(std::move(res[i])), opt.features_version));
+        }
+        return out;
+    }
+};
+
+}  // namespace bliss

@@ -173,3 +173,17 @@ def test_two_rank_gloo_shard_and_all_gather(tmp_path):
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {rank} ok" in o
+
+
+def test_cpp_host_mirror_compiles(tmp_path, bliss):
+    """The C++ mirror of the reference interface builds against include/blissgpu.h + libblissgpu.so and,
+    without a GPU, fails loudly instead of falling back to a CPU path."""
+    import torch
+
+    exe = tmp_path / "test_bliss_audio"
+    libdir = os.path.join(ROOT, "bliss-rs_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "test_bliss_audio.cpp"), "-o",
+                           str(exe), f"-L{libdir}", "-lblissgpu", f"-Wl,-rpath,{libdir}"])
+    if not torch.cuda.is_available():
+        out = subprocess.run([str(exe), "a", "b"], capture_output=True, text=True)
+        assert out.returncode != 0 and "no usable HIP device" in out.stderr
