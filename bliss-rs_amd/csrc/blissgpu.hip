@@ -3,6 +3,7 @@
 // src/song/decoder.rs:282-331, and of the five per-descriptor threads, src/song/mod.rs:432-491).
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -32,7 +33,7 @@ int fail(int code, const char* what, const char* detail) {
 
 const char* const kKernelNames[K_COUNT] = {
     "pcm_stats_kernel", "fft512_kernel",     "onset_kernel",      "beat_kernel",   "stft8192_kernel", "tune_select_kernel",
-    "tune_pass2_kernel", "tune_final_kernel", "chroma_kernel",     "finalize_kernel", "pairwise_kernel", "synth_kernel"};
+    "tune_pass2_kernel", "tune_final_kernel", "chroma_kernel",     "summary_kernel", "assemble_kernel", "pairwise_kernel", "synth_kernel"};
 
 struct EventPair { hipEvent_t a, b; };
 
@@ -59,7 +60,10 @@ struct DevBuf {
 struct blissgpu_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // chroma chain + assembly (the caller-visible stream)
+    hipStream_t aux_stream = nullptr;  // tempo / timbral / loudness chain, joined before the assembly
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool serial = false;               // BLISSGPU_SERIAL=1: single stream (clean per-kernel timings)
     uint64_t ws_limit = 96ull << 30;
     // tables
     float2 *tw8192 = nullptr, *tw512 = nullptr;
@@ -83,21 +87,23 @@ struct blissgpu_ctx {
 
 namespace {
 
-struct Prof {
+struct Prof {  // HIP events around one launch, on the stream the kernel is launched on
     blissgpu_ctx* c;
     int k;
+    hipStream_t st;
     EventPair ev{};
     bool on;
-    Prof(blissgpu_ctx* ctx, int kernel) : c(ctx), k(kernel), on(ctx->profiling) {
+    Prof(blissgpu_ctx* ctx, int kernel, hipStream_t stream = nullptr)
+        : c(ctx), k(kernel), st(stream ? stream : ctx->stream), on(ctx->profiling) {
         if (on) {
             (void)hipEventCreate(&ev.a);
             (void)hipEventCreate(&ev.b);
-            (void)hipEventRecord(ev.a, c->stream);
+            (void)hipEventRecord(ev.a, st);
         }
     }
     ~Prof() {
         if (on) {
-            (void)hipEventRecord(ev.b, c->stream);
+            (void)hipEventRecord(ev.b, st);
             c->events[k].push_back(ev);
         }
     }
@@ -209,7 +215,7 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
         }
         pfx_e[i + 1] = pfx_e[i] + (d.ok ? (d.n_e + 15) / 16 : 0);
         pfx_f[i + 1] = pfx_f[i] + (d.ok ? (d.n_f + F512_TILE - 1) / F512_TILE : 0);
-        pfx_c[i + 1] = pfx_c[i] + (d.ok ? d.n_c : 0);
+        pfx_c[i + 1] = pfx_c[i] + (d.ok ? (d.n_c + STFT_TILE - 1) / STFT_TILE : 0);
         pfx_ct[i + 1] = pfx_ct[i] + (d.ok ? (d.n_c + CH_TILE - 1) / CH_TILE : 0);
     }
     // ---- descriptors to the device (pinned staging, one async copy) ----
@@ -257,6 +263,7 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
         m.take<double>((size_t)b.tiles_ct * 10 + 16);
         m.take<TempoState>(ns);
         m.take<float>((size_t)ns * max_runs); m.take<uint32_t>((size_t)ns * max_runs);
+        m.take<float>((size_t)ns * 16);
         need = m.off + 4096;
     }
     if (need > c->slab.cap) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -275,25 +282,35 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
     w.tempo = m.take<TempoState>(ns);
     w.run_bpm = m.take<float>((size_t)ns * max_runs); w.run_cnt = m.take<uint32_t>((size_t)ns * max_runs);
     w.runs_pitch = max_runs;
+    w.summary = m.take<float>((size_t)ns * 16);
 
     c->last_ws = w;
     c->last_songs = songs;
 
-    hipStream_t st = c->stream;
-    HIP_TRY(hipMemsetAsync(w.h1, 0, (size_t)ns * H1_BINS * 4, st));
-    HIP_TRY(hipMemsetAsync(w.hist100, 0, (size_t)ns * N_TUNING * 4, st));
-
-    // tempo + timbral + zcr + loudness chain
+    // The reference runs the five descriptors as scoped threads (src/song/mod.rs:432-491).  Here the two
+    // FFT-heavy kernels run back to back on the caller-visible stream; the latency-bound tails of the
+    // tempo / timbral chains (one workgroup per song: sequential beat tracker, sequential summaries)
+    // run beside the chroma chain on the aux stream and are joined before the feature rows are written.
+    hipStream_t st = c->stream, sb = c->serial ? c->stream : c->aux_stream;
     { Prof p(c, K_PCM_STATS); launch_pcm_stats(b, w, st); }
     { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st); }
     { Prof p(c, K_ONSET); launch_onset(b, w, st); }
-    { Prof p(c, K_BEAT); launch_beat(b, w, c->tables, st); }
-    // chroma chain
+    if (!c->serial) {
+        HIP_TRY(hipEventRecord(c->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(sb, c->ev_fork, 0));
+    }
+    { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
+    { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
+    if (!c->serial) HIP_TRY(hipEventRecord(c->ev_join, sb));
+
+    HIP_TRY(hipMemsetAsync(w.h1, 0, (size_t)ns * H1_BINS * 4, st));
+    HIP_TRY(hipMemsetAsync(w.hist100, 0, (size_t)ns * N_TUNING * 4, st));
     { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st); }
     { Prof p(c, K_TUNE_SELECT); launch_tune_select(b, w, st); }
     { Prof p(c, K_TUNE_PASS2); launch_tune_pass2(b, w, st); }
     { Prof p(c, K_TUNE_FINAL); launch_tune_final(b, w, st); }
     { Prof p(c, K_CHROMA); launch_chroma(b, w, c->tables, st); }
+    if (!c->serial) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
     { Prof p(c, K_FINALIZE); launch_finalize(b, w, features_version, d_out, c->dbg_tuning.p, c->dbg_nbpms.p, st); }
     HIP_TRY(hipGetLastError());
     return BLISSGPU_OK;
@@ -351,6 +368,11 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
     hipError_t se = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(BLISSGPU_ERR_HIP, "hipStreamCreate", hipGetErrorString(se)); }
     c->stream = c->own_stream;
+    se = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (se != hipSuccess) { blissgpu_ctx_destroy(c); return fail(BLISSGPU_ERR_HIP, "aux stream/events", hipGetErrorString(se)); }
+    if (const char* e = getenv("BLISSGPU_SERIAL")) c->serial = (e[0] == '1');
     int rc = build_tables(c);
     if (rc) { blissgpu_ctx_destroy(c); return rc; }
     *out = c;
@@ -367,6 +389,9 @@ int blissgpu_ctx_destroy(blissgpu_ctx* c) {
     (void)hipFree(c->bt_rwv); (void)hipFree(c->bt_dfwv); (void)hipFree(c->chroma_bank);
     c->slab.release(); c->desc.release(); c->dbg_tuning.release(); c->dbg_nbpms.release();
     if (c->h_desc) (void)hipHostFree(c->h_desc);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return BLISSGPU_OK;

@@ -27,8 +27,9 @@ constexpr int PIP_LO = 57, PIP_HI = 1483; // centre bins visited by pip_track at
 constexpr int PIP_MAX_PER_FRAME = 714;    // peaks cannot be adjacent: ceil(1427/2)
 constexpr int H1_BINS = 8192;             // coarse magnitude histogram: f32 bit pattern >> 18
 constexpr int BT_WINLEN = 512, BT_STEP = 128, BT_LAGLEN = 128;  // src/aubio.rs:1337-1341, 920-922
-constexpr int F512_TILE = 64;             // timbral frames per workgroup in the FFT-512 kernel
+constexpr int F512_TILE = 256;            // FFT-512 frames per workgroup (16 lane-groups x 16 consecutive frames)
 constexpr int CH_TILE = 64;               // chroma frames per workgroup in the contraction kernel
+constexpr int STFT_TILE = 16;             // chroma frames per workgroup in the STFT kernel
 
 // Per-song descriptor, built on the host, read by every kernel.
 struct SongDesc {
@@ -85,6 +86,7 @@ enum KernelId : int {
     K_TUNE_PASS2,
     K_TUNE_FINAL,
     K_CHROMA,
+    K_SUMMARY,
     K_FINALIZE,
     K_PAIRWISE,
     K_SYNTH,
@@ -123,6 +125,7 @@ struct Workspace {
     float* run_bpm;         // [n_songs][runs_pitch] bpm after each beat-tracker run
     uint32_t* run_cnt;      // [n_songs][runs_pitch] beats recorded while that bpm was current
     uint32_t runs_pitch;
+    float* summary;         // [n_songs][16] features 1..9 (zcr, timbral, loudness summaries)
 };
 
 struct Batch {
@@ -132,7 +135,7 @@ struct Batch {
     // tile prefix arrays (device), n_songs+1 entries each
     const uint32_t* pfx_e;    // pcm-stats tiles
     const uint32_t* pfx_f;    // fft512 tiles
-    const uint32_t* pfx_c;    // chroma frames
+    const uint32_t* pfx_c;    // STFT tiles (STFT_TILE chroma frames each)
     const uint32_t* pfx_ct;   // chroma contraction tiles
     uint32_t tiles_e, tiles_f, tiles_c, tiles_ct;
     uint64_t total_b;         // tempo frames in the batch
@@ -149,6 +152,7 @@ void launch_tune_select(const Batch&, const Workspace&, hipStream_t);
 void launch_tune_pass2(const Batch&, const Workspace&, hipStream_t);
 void launch_tune_final(const Batch&, const Workspace&, hipStream_t);
 void launch_chroma(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
+void launch_summary(const Batch&, const Workspace&, hipStream_t);
 void launch_finalize(const Batch&, const Workspace&, uint32_t features_version, float* d_out, int32_t* dbg_tuning,
                      uint32_t* dbg_nbpms, hipStream_t);
 void launch_chroma_bank(double* bank, hipStream_t);

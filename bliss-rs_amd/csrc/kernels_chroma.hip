@@ -17,6 +17,7 @@
 #include <float.h>
 
 #include "device_utils.hpp"
+#include "fft_r16.hpp"
 #include "internal.hpp"
 
 namespace bg {
@@ -78,11 +79,29 @@ void launch_chroma_bank(double* bank, hipStream_t st) {
 // pip_track peak test on three neighbouring magnitudes (src/chroma.rs:317-327) + the pitch-residue
 // bin pitch_tuning would file it under (:342-351).  f64, no contraction: identical in both passes.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool pip_peak(float sb, float se, float sa, double ref, int c, double* mag_out,
-                                         int* pb_out) {
+// the peak condition alone (:318): cheap, evaluated by every lane; f32 -> f64 widening is monotone,
+// so the two neighbour comparisons give the same outcome in f32
+__device__ __forceinline__ bool pip_is_peak(float sb, float se, float sa, double ref) {
+    return (sa <= se) && (sb < se) && ((double)se > ref);
+}
+
+// append the centre bins flagged by `is_peak` to an LDS list (order is irrelevant downstream)
+__device__ __forceinline__ void wave_append(bool is_peak, int c, uint16_t* list, uint32_t* count) {
+    const uint64_t mask = __ballot(is_peak);
+    if (mask == 0) return;
+    const uint32_t lane = (uint32_t)lane_id();
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, 0, WAVE);
+    if (is_peak) list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)c;
+}
+
+__device__ __forceinline__ bool pip_peak_core(float sb, float se, float sa, double ref, int c, double* mag_out,
+                                              double* pitch_out) {
 #pragma clang fp contract(off)
+    if (!(sa <= se && sb < se)) return false;
     const double before = (double)sb, elem = (double)se, after = (double)sa;
-    if (!(elem > ref && after <= elem && before < elem)) return false;
+    if (!(elem > ref)) return false;
     const double avg = 0.5 * (after - before);
     double shift = 2.0 * elem - after - before;
     if (fabs(shift) < DBL_MIN) shift += 1.0;
@@ -90,14 +109,27 @@ __device__ __forceinline__ bool pip_peak(float sb, float se, float sa, double re
     const double pitch = ((double)c + shift) * 22050.0 / 8192.0;
     if (!(pitch > 0.0)) return false;  // estimate_tuning keeps p > 0 only (:370-375)
     *mag_out = elem + 0.5 * avg * shift;
+    *pitch_out = pitch;
+    return true;
+}
+
+// magnitude only (pass 1)
+__device__ __forceinline__ bool pip_peak_mag(float sb, float se, float sa, double ref, int c, double* mag_out) {
+    double pitch;
+    return pip_peak_core(sb, se, sa, ref, c, mag_out, &pitch);
+}
+
+// pitch_tuning's residue bin of a peak (:342-351)
+__device__ __forceinline__ int pitch_bin(double pitch) {
+#pragma clang fp contract(off)
     double x = log2(pitch / (440.0 / 16.0));
-    x = fmod(12.0 * x, 1.0);
+    x = 12.0 * x;
+    x = x - trunc(x);  // == fmod(x, 1.0) exactly (the subtraction of the integer part is exact in binary fp)
     if (x >= 0.5) x -= 1.0;
     const double q = (x - -0.5) / 0.01;
     int idx = (q > 0.0) ? (int)q : 0;
     if (idx > N_TUNING - 1) idx = N_TUNING - 1;
-    *pb_out = idx;
-    return true;
+    return idx;
 }
 
 __device__ __forceinline__ uint32_t coarse_bin(double mag) {
@@ -107,77 +139,179 @@ __device__ __forceinline__ uint32_t coarse_bin(double mag) {
 
 // ------------------------------------------------------------------------------------------------
 // STFT 8192 / hop 2205
+//
+// One workgroup (256 threads) transforms STFT_FRAMES_PER_WG consecutive frames of one song.  A frame's
+// 8192 real samples are packed as 4096 complex values z[n] = x[2n] + i x[2n+1] and transformed as
+// 16 x 16 x 16: every thread keeps 16 complex values in registers and runs three radix-16 passes with
+// two padded (bank-conflict-free) LDS transposes in between; a third LDS round trip pairs Z[k] with
+// Z[4096-k] for the real-input split.  The window (read once per workgroup) stays in registers.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stft8192_kernel(const float* __restrict__ pcm,
+constexpr int STFT_FRAMES_PER_WG = STFT_TILE;
+constexpr int LHIST_BINS = 512;  // 16 octaves of 32 coarse bins
+constexpr int EX1_PITCH = 258;   // k1-major rows of 256 (+2): pass-2 reads hit 64 distinct banks
+constexpr int EX2_PITCH = 272;   // j1-major rows of 256 (+16): shifts odd rows by 32 banks
+constexpr int STFT_LDS = 16 * EX2_PITCH;  // float2 elements (34 816 B)
+
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+// 8-byte load through a buffer descriptor: 32-bit lane offset + scalar offset (no 64-bit address VGPRs)
+__device__ __forceinline__ float2 buf_load_f2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+
+__device__ __forceinline__ long reflect_index(long p, long n) {
+    // numpy mode="reflect" on the original signal (src/utils.rs:11-24); pad = 4096 <= n - 2 always holds
+    if (p < 0) p = -p;
+    else if (p >= n) p = 2 * n - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restrict__ pcm,
                                                        const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                        const uint32_t* __restrict__ pfx_c,
                                                        const float* __restrict__ hann,
                                                        const float2* __restrict__ tw, float* __restrict__ spec,
                                                        float* __restrict__ frame_max, uint32_t* __restrict__ h1) {
-    __shared__ float2 bufA[4096];
-    __shared__ float2 bufB[4096];
+    __shared__ float2 lds[STFT_LDS];
     __shared__ float red[4];
+    // peaks are first counted in an LDS window of the coarse-magnitude histogram (a frame's peaks lie
+    // within [0.1 max, ~max], i.e. ~110 coarse bins) and flushed once per workgroup: global atomics on
+    // a song's few hot histogram lines would otherwise serialise at the L2
+    __shared__ uint32_t lhist[LHIST_BINS];
+    __shared__ uint32_t lhist_base;
+    __shared__ uint16_t peak_list[PIP_MAX_PER_FRAME + 2];
+    __shared__ uint32_t peak_count;
     const uint32_t s = find_segment(pfx_c, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
-    const uint32_t f = blockIdx.x - pfx_c[s];
+    const uint32_t tile = blockIdx.x - pfx_c[s];
     const float* __restrict__ x = pcm + sd.pcm_off;
-    const int tid = threadIdx.x;
+    const int t = threadIdx.x;
     const long n = (long)sd.n;
+    const int lo4 = t & 15, hi4 = t >> 4;
 
-    // reflect_pad (src/utils.rs:11-24) + window (:37-39, :49)
-    float* xin = reinterpret_cast<float*>(bufA);
-    const long w0 = (long)f * HOP_C - W8192 / 2;
-#pragma unroll 4
-    for (int j = 0; j < 32; j++) {
-        const int i = tid + 256 * j;
-        long p = w0 + i;
-        if (p < 0) p = -p;
-        else if (p >= n) p = 2 * n - 2 - p;
-        xin[i] = x[p] * hann[i];
-    }
-    __syncthreads();
-    // 4096-point complex FFT: 6 radix-4 passes, ping-pong A -> B -> ... -> A
-    {
-        float2* src = bufA;
-        float2* dst = bufB;
-#pragma unroll
-        for (int Ns = 1; Ns < 4096; Ns *= 4) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) stockham_r4<4096>(src, dst, tid + 256 * q, Ns, tw, 2);
-            __syncthreads();
-            float2* t = src; src = dst; dst = t;
-        }
-    }
-    // split into the 4097 real-FFT bins, magnitude in f32 (:60)
-    float* mags = reinterpret_cast<float*>(bufB);
-    float* row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
-    float mx = 0.0f;
-    for (int k = tid; k <= 4096; k += 256) {
-        float m;
-        if (k == 0 || k == 4096) {
-            const float2 z0 = bufA[0];
-            m = fabsf(k == 0 ? z0.x + z0.y : z0.x - z0.y);
-        } else {
-            const float2 X = real_split(bufA[k], bufA[4096 - k], tw[k]);
-            m = sqrtf(X.x * X.x + X.y * X.y);
-        }
-        mags[k] = m;
-        row[k] = m;
-        mx = fmaxf(mx, m);
-    }
-    if (tid < CBINS_PAD - CBINS) row[CBINS + tid] = 0.0f;
-    mx = wave_max(mx);
-    if (lane_id() == 0) red[wave_id()] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (tid == 0) frame_max[sd.c_off + f] = mx;
-    // pip_track pass 1: count peaks by coarse magnitude bin
-    const double ref = 0.1 * (double)mx;
+    // descriptors: window table (8192 f32) and twiddle table (8192 float2); wave-uniform
+    const __amdgpu_buffer_rsrc_t r_hann = __builtin_amdgcn_make_buffer_rsrc((void*)hann, 0, W8192 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_tw = __builtin_amdgcn_make_buffer_rsrc((void*)tw, 0, W8192 * 8, 0x00020000);
+    const uint32_t t8 = 8u * (uint32_t)t;  // byte offset of (x[2t], x[2t+1]) / (hann[2t], hann[2t+1])
     uint32_t* hist = h1 + (size_t)s * H1_BINS;
-    for (int c = PIP_LO + tid; c <= PIP_HI; c += 256) {
-        double mag;
-        int pb;
-        if (pip_peak(mags[c - 1], mags[c], mags[c + 1], ref, c, &mag, &pb)) atomicAdd(&hist[coarse_bin(mag)], 1u);
+    for (int i = t; i < LHIST_BINS; i += 256) lhist[i] = 0;
+    bool have_base = false;
+
+#pragma unroll 1
+    for (int fi = 0; fi < STFT_FRAMES_PER_WG; fi++) {
+        const uint32_t f = tile * STFT_FRAMES_PER_WG + fi;
+        if (f >= sd.n_c) break;  // uniform
+        const long w0 = (long)f * HOP_C - W8192 / 2;
+        float2 v[16];
+        // ---- load + window (reflect only at the song edges) ----
+        if (w0 >= 0 && w0 + W8192 <= n) {
+            const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + w0), 0, W8192 * 4, 0x00020000);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) {
+                const float2 w = buf_load_f2(r_hann, t8, 2048u * n1);
+                const float2 xv = buf_load_f2(r_x, t8, 2048u * n1);
+                v[n1] = make_float2(xv.x * w.x, xv.y * w.y);
+            }
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) {
+                const long p = w0 + 2 * (256 * n1 + t);
+                const float2 w = buf_load_f2(r_hann, t8, 2048u * n1);
+                v[n1] = make_float2(x[reflect_index(p, n)] * w.x, x[reflect_index(p + 1, n)] * w.y);
+            }
+        }
+        // ---- pass 1: DFT over n1 at n2 = t; twiddle W_4096^(t*k1) ----
+        radix16(v);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], buf_load_f2(r_tw, 16u * (uint32_t)t * k1, 0));
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++) lds[k1 * EX1_PITCH + t] = v[k1];
+        __syncthreads();
+        // ---- pass 2: thread (k1 = lo4, m2 = hi4): DFT over m1; twiddle W_256^(m2*j1) ----
+#pragma unroll
+        for (int m1 = 0; m1 < 16; m1++) v[m1] = lds[lo4 * EX1_PITCH + 16 * m1 + hi4];
+        radix16(v);
+#pragma unroll
+        for (int j1 = 1; j1 < 16; j1++) v[j1] = cmul(v[j1], buf_load_f2(r_tw, 256u * (uint32_t)hi4 * j1, 0));
+        __syncthreads();
+#pragma unroll
+        for (int j1 = 0; j1 < 16; j1++) lds[j1 * EX2_PITCH + t] = v[j1];  // = j1*272 + m2*16 + k1
+        __syncthreads();
+        // ---- pass 3: thread (k1 = lo4, j1 = hi4): DFT over m2 -> Z[t + 256*j2] ----
+#pragma unroll
+        for (int m2 = 0; m2 < 16; m2++) v[m2] = lds[hi4 * EX2_PITCH + 16 * m2 + lo4];
+        radix16(v);
+        __syncthreads();
+#pragma unroll
+        for (int j2 = 0; j2 < 16; j2++) lds[t + 256 * j2] = v[j2];
+        __syncthreads();
+        // ---- real-input split + magnitude (src/utils.rs:60), bins k = t + 256*j ----
+        float m[16];
+        float mx = 0.0f;
+        const float2 z0 = lds[0];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int k = t + 256 * j;
+            if (k == 0) {
+                m[j] = fabsf(z0.x + z0.y);
+            } else {
+                const float2 X = real_split(v[j], lds[4096 - k], buf_load_f2(r_tw, t8, 2048u * j));
+                m[j] = sqrtf(X.x * X.x + X.y * X.y);
+            }
+            mx = fmaxf(mx, m[j]);
+        }
+        const float nyq = fabsf(z0.x - z0.y);
+        mx = fmaxf(mx, nyq);
+        float* row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
+#pragma unroll
+        for (int j = 0; j < 16; j++) row[t + 256 * j] = m[j];
+        if (t < CBINS_PAD - 4096) row[4096 + t] = (t == 0) ? nyq : 0.0f;  // bin 4096 + zero padding
+        mx = wave_max(mx);
+        __syncthreads();  // all split reads of lds are done
+        float* mags = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int j = 0; j < 16; j++) mags[t + 256 * j] = m[j];
+        if (lane_id() == 0) red[wave_id()] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (t == 0) frame_max[sd.c_off + f] = mx;
+        if (!have_base) {  // uniform: anchor the LDS window LHIST_BINS/2 bins below the first frame's maximum
+            if (t == 0) {
+                const uint32_t top = coarse_bin((double)mx);
+                lhist_base = top > (uint32_t)(LHIST_BINS * 3 / 4) ? top - (uint32_t)(LHIST_BINS * 3 / 4) : 0u;
+            }
+            have_base = true;
+            __syncthreads();
+        }
+        const uint32_t lbase = lhist_base;
+        // ---- pip_track pass 1: count peaks by coarse magnitude bin.  Cheap test by every lane, the
+        // peaks (about a third of the bins) are compacted so the f64 part runs on full wavefronts ----
+        const double ref = 0.1 * (double)mx;
+        if (t == 0) peak_count = 0;
+        __syncthreads();
+        for (int c = PIP_LO + t; c < PIP_LO + 6 * 256; c += 256) {  // uniform trip count (ballots inside)
+            const bool pk = (c <= PIP_HI) && pip_is_peak(mags[c - 1], mags[c], mags[c + 1], ref);
+            wave_append(pk, c, peak_list, &peak_count);
+        }
+        __syncthreads();
+        const int n_peaks = (int)peak_count;
+        for (int i = t; i < n_peaks; i += 256) {
+            const int c = peak_list[i];
+            double mag;
+            if (pip_peak_mag(mags[c - 1], mags[c], mags[c + 1], ref, c, &mag)) {
+                const uint32_t b = coarse_bin(mag), rel = b - lbase;
+                if (rel < (uint32_t)LHIST_BINS) atomicAdd(&lhist[rel], 1u);
+                else atomicAdd(&hist[b], 1u);
+            }
+        }
+        __syncthreads();  // mags (lds) is reused by the next frame
+    }
+    if (have_base) {
+        const uint32_t lbase = lhist_base;
+        for (int i = t; i < LHIST_BINS; i += 256) {
+            const uint32_t c = lhist[i];
+            if (c) atomicAdd(&hist[lbase + i], c);
+        }
     }
 }
 
@@ -252,6 +386,8 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
                                                          double* __restrict__ cand_mag,
                                                          uint8_t* __restrict__ cand_pb) {
     __shared__ uint32_t hist[N_TUNING];
+    __shared__ uint16_t peak_list[4][PIP_MAX_PER_FRAME + 2];
+    __shared__ uint32_t peak_count[4];
     const uint32_t s = find_segment(pfx_ct, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
     const uint32_t tile = blockIdx.x - pfx_ct[s];
@@ -266,17 +402,26 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
         if (f >= sd.n_c) break;
         const float* row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
         const double ref = 0.1 * (double)frame_max[sd.c_off + f];
-        for (int c = PIP_LO + lane; c <= PIP_HI; c += WAVE) {
-            double mag;
-            int pb;
-            if (pip_peak(row[c - 1], row[c], row[c + 1], ref, c, &mag, &pb)) {
+        // cheap test by every lane, then the peaks are processed densely (one per lane)
+        if (lane == 0) peak_count[wave] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int c = PIP_LO + lane; c < PIP_LO + 23 * WAVE; c += WAVE) {
+            const bool pk = (c <= PIP_HI) && pip_is_peak(row[c - 1], row[c], row[c + 1], ref);
+            wave_append(pk, c, peak_list[wave], &peak_count[wave]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int n_peaks = (int)peak_count[wave];
+        for (int i = lane; i < n_peaks; i += WAVE) {
+            const int c = peak_list[wave][i];
+            double mag, pitch;
+            if (pip_peak_core(row[c - 1], row[c], row[c + 1], ref, c, &mag, &pitch)) {
                 const uint32_t b = coarse_bin(mag);
                 if (b > b_hi) {
-                    atomicAdd(&hist[pb], 1u);
+                    atomicAdd(&hist[pitch_bin(pitch)], 1u);
                 } else if (b >= b_lo) {
                     const uint32_t slot = atomicAdd(&ts->n_cand, 1u);
                     cand_mag[sd.cand_off + slot] = mag;
-                    cand_pb[sd.cand_off + slot] = (uint8_t)pb;
+                    cand_pb[sd.cand_off + slot] = (uint8_t)pitch_bin(pitch);
                 }
             }
         }
@@ -443,18 +588,20 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
         if (fj >= sd.n_c) fj = sd.n_c - 1;
         const double* __restrict__ arow = bank + ((size_t)slot * BANK_ROWS + i16) * CBINS_PAD + 4 * g;
         const float* __restrict__ brow = spec + (sd.c_off + fj) * (size_t)CBINS_PAD + 4 * g;
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
+        // two independent accumulator chains so consecutive MFMAs do not wait on each other
+        double4_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
         for (int st = 0; st < CBINS_PAD / 16; st++) {
             const double4_t a = *reinterpret_cast<const double4_t*>(arow + 16 * st);
             const float4 b = *reinterpret_cast<const float4*>(brow + 16 * st);
             const double b0 = (double)b.x * (double)b.x, b1 = (double)b.y * (double)b.y;
             const double b2 = (double)b.z * (double)b.z, b3 = (double)b.w * (double)b.w;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b1, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b1, acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.z, b2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.w, b3, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.w, b3, acc2, 0, 0, 0);
         }
+        acc += acc2;
         // C[row = g + 4r][col = i16]: rows are chroma classes, columns are frames
 #pragma unroll
         for (int r = 0; r < 3; r++) tile_c[wave][i16][g + 4 * r] = acc[r];

@@ -11,169 +11,224 @@
 //     is |Re X[256]| (src/aubio.rs:240-261, 16-58; src/timbral.rs:154-209; src/utils.rs:101-117)
 //   * for odd frames, the SpecFlux onset value over the correct 257 bins (src/aubio.rs:455-467).
 //
-// Mapping: one wavefront per frame, frames of a wave processed in increasing order so the previous
-// tempo frame's magnitudes stay in LDS.  The 512 real samples are packed as 256 complex values and
-// transformed by four Stockham radix-4 passes in LDS (one butterfly per lane), then split.
+// Mapping: a 16-lane group owns one frame at a time (4 frames per wavefront, 16 per workgroup).  The
+// 512 real samples are packed as 256 complex values = 16 x 16: each lane holds 16 of them in registers,
+// runs a radix-16 pass, transposes inside its group through a padded LDS tile, runs the second radix-16
+// pass, and a second LDS round trip re-orders the spectrum so that lane l ends up with the 16
+// CONSECUTIVE bins 16l..16l+15 (needed by the rolloff prefix sum) and with Z[256-k] for the real-input
+// split.  Reductions stay inside the 16-lane row (DPP).  A group walks FRAMES_PER_GROUP consecutive
+// frames so the previous tempo frame's magnitudes stay in registers (one halo FFT per group).
 #include "device_utils.hpp"
+#include "fft_r16.hpp"
 #include "internal.hpp"
 
 namespace bg {
 
-constexpr int FRAMES_PER_WAVE = F512_TILE / 4;
+constexpr int GROUPS_PER_WG = 16;
+constexpr int FRAMES_PER_GROUP = F512_TILE / GROUPS_PER_WG;
+constexpr int GRP_PITCH = 272;  // float2 per group tile: 16 rows of 17, and == 128 B (mod 256 B) between groups
 
-struct WaveLds {
-    float2 a[256];
-    float2 b[256];
-    float prevmag[260];  // 257 magnitudes of the previous tempo frame (+pad)
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 buf_load_f2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+
+// ---- reductions across the 16 lanes of a DPP row ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+template <typename T>
+__device__ __forceinline__ T row16_sum(T v) {  // every lane of the row gets the row total
+    v += dpp_mov<DPP_QUAD_XOR1>(v);
+    v += dpp_mov<DPP_QUAD_XOR2>(v);
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov<DPP_ROW_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_scan_incl(float v) {  // row_shr:n with zero fill
+    v += dpp_mov<0x111>(v);
+    v += dpp_mov<0x112>(v);
+    v += dpp_mov<0x114>(v);
+    v += dpp_mov<0x118>(v);
+    return v;
+}
+
+struct FrameMags {
+    float m[16];  // |X[16l + e]|
+    float nyq;    // |X[256]| (every lane)
 };
 
-// Computes the 257 magnitudes of FFT frame k of song sd into registers:
-// lane l gets |X[4l..4l+3]| in m[0..3]; the Nyquist magnitude |X[256]| is returned in *nyq (all lanes).
-__device__ __forceinline__ void fft512_frame(const float* __restrict__ x, long k, WaveLds& lds,
-                                             const float* __restrict__ hannz, const float2* __restrict__ tw512,
-                                             float m[4], float* nyq) {
-    const int lane = lane_id();
-    const long start = (k + 1) * HOP_T - W512;
-    float* xin = reinterpret_cast<float*>(lds.a);
+// 257 magnitudes of FFT frame k: lane l of the group gets bins 16l..16l+15
+__device__ __forceinline__ void fft512_frame(__amdgpu_buffer_rsrc_t r_x, long rel_start, int l, float2* tile,
+                                             __amdgpu_buffer_rsrc_t r_win, __amdgpu_buffer_rsrc_t r_tw,
+                                             FrameMags& out) {
+    float2 v[16];
+    // z[16 n1 + l] = (x[s + 32 n1 + 2l], x[s + 32 n1 + 2l + 1]); samples before the song start are 0
+    // (the reference's zero-initialised sliding buffer); s is a multiple of 128, so pairs never straddle 0
+    const uint32_t loff = 8u * (uint32_t)l;
+    if (rel_start >= 0) {
+        const uint32_t xoff = (uint32_t)((rel_start + 2 * l) * 4);
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int i = lane + 64 * j;
-        const long idx = start + i;
-        const float v = (idx >= 0) ? x[idx] : 0.0f;
-        xin[i] = v * hannz[i];
-    }
-    __builtin_amdgcn_wave_barrier();
-    stockham_r4<256>(lds.a, lds.b, lane, 1, tw512, 2);
-    __builtin_amdgcn_wave_barrier();
-    stockham_r4<256>(lds.b, lds.a, lane, 4, tw512, 2);
-    __builtin_amdgcn_wave_barrier();
-    stockham_r4<256>(lds.a, lds.b, lane, 16, tw512, 2);
-    __builtin_amdgcn_wave_barrier();
-    stockham_r4<256>(lds.b, lds.a, lane, 64, tw512, 2);
-    __builtin_amdgcn_wave_barrier();
-    const float2* z = lds.a;
-    const float2 z0 = z[0];
+        for (int n1 = 0; n1 < 16; n1++) {
+            const float2 xv = buf_load_f2(r_x, xoff, 128u * n1);
+            const float2 w = buf_load_f2(r_win, loff, 128u * n1);
+            v[n1] = make_float2(xv.x * w.x, xv.y * w.y);
+        }
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const int kk = 4 * lane + e;
-        const float2 zk = z[kk];
-        const float2 zm = z[(256 - kk) & 255];
-        const float2 X = real_split(zk, zm, tw512[kk]);
-        m[e] = (kk == 0) ? fabsf(z0.x + z0.y) : sqrtf(X.x * X.x + X.y * X.y);
+        for (int n1 = 0; n1 < 16; n1++) {
+            const long idx = rel_start + 32 * n1 + 2 * l;
+            float2 xv = make_float2(0.0f, 0.0f);
+            if (idx >= 0) xv = buf_load_f2(r_x, (uint32_t)(idx * 4), 0);
+            const float2 w = buf_load_f2(r_win, loff, 128u * n1);
+            v[n1] = make_float2(xv.x * w.x, xv.y * w.y);
+        }
     }
-    *nyq = fabsf(z0.x - z0.y);
+    radix16(v);  // over n1 -> A[k1]
+#pragma unroll
+    for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], buf_load_f2(r_tw, 16u * (uint32_t)(l * k1), 0));  // W_256^(l*k1)
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) tile[k1 * 17 + l] = v[k1];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; n2++) v[n2] = tile[l * 17 + n2];
+    __builtin_amdgcn_wave_barrier();
+    radix16(v);  // over n2 -> Z[l + 16 k2]
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) tile[k2 * 17 + l] = v[k2];  // Z[k] at k + (k >> 4)
+    __builtin_amdgcn_wave_barrier();
+    const float2 z0 = tile[0];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const float2 zk = tile[l * 17 + e];
+        // Z[256 - k], k = 16 l + e  (k = 0 pairs with itself)
+        const int mi = (e == 0) ? ((l == 0) ? 0 : 17 * (16 - l)) : (17 * (15 - l) + 16 - e);
+        const float2 zm = tile[mi];
+        const float2 X = real_split(zk, zm, buf_load_f2(r_tw, 128u * (uint32_t)l, 8u * e));  // W_512^k = tw512[k]
+        out.m[e] = sqrtf(X.x * X.x + X.y * X.y);
+    }
+    if (l == 0) out.m[0] = fabsf(z0.x + z0.y);
+    out.nyq = fabsf(z0.x - z0.y);
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(256) void fft512_kernel(const float* __restrict__ pcm,
-                                                     const SongDesc* __restrict__ songs, uint32_t n_songs,
-                                                     const uint32_t* __restrict__ pfx_f,
-                                                     const float* __restrict__ hannz,
-                                                     const float2* __restrict__ tw512, float* __restrict__ centroid,
-                                                     float* __restrict__ rolloff, float* __restrict__ flatness,
-                                                     float* __restrict__ flux) {
-    __shared__ WaveLds lds_all[4];
+__global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict__ pcm,
+                                                        const SongDesc* __restrict__ songs, uint32_t n_songs,
+                                                        const uint32_t* __restrict__ pfx_f,
+                                                        const float* __restrict__ hannz,
+                                                        const float2* __restrict__ tw512,
+                                                        float* __restrict__ centroid, float* __restrict__ rolloff,
+                                                        float* __restrict__ flatness, float* __restrict__ flux) {
+    __shared__ float2 lds[GROUPS_PER_WG * GRP_PITCH];
     const uint32_t s = find_segment(pfx_f, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
-    const uint32_t tile = blockIdx.x - pfx_f[s];
-    const float* __restrict__ x = pcm + sd.pcm_off;
-    const int lane = lane_id(), wave = wave_id();
-    WaveLds& lds = lds_all[wave];
+    const uint32_t tile_idx = blockIdx.x - pfx_f[s];
+    const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+    float2* tile = lds + grp * GRP_PITCH;
 
-    const long k_begin = (long)tile * F512_TILE + (long)wave * FRAMES_PER_WAVE;  // even
-    if (k_begin >= (long)sd.n_f) return;
-    const long k_end = (k_begin + FRAMES_PER_WAVE < (long)sd.n_f) ? k_begin + FRAMES_PER_WAVE : (long)sd.n_f;
+    const long k_begin = (long)tile_idx * F512_TILE + (long)grp * FRAMES_PER_GROUP;  // even
+    const long k_end = (k_begin + FRAMES_PER_GROUP < (long)sd.n_f) ? k_begin + FRAMES_PER_GROUP : (long)sd.n_f;
 
-    float m[4], nyq;
-    // halo: magnitudes of the previous tempo frame (FFT frame k_begin-1), zeros before the song starts
-    if (k_begin >= 1) {
-        fft512_frame(x, k_begin - 1, lds, hannz, tw512, m, &nyq);
-#pragma unroll
-        for (int e = 0; e < 4; e++) lds.prevmag[4 * lane + e] = m[e];
-        if (lane == 0) lds.prevmag[256] = nyq;
+    // descriptor over this workgroup's slice of the song (keeps lane offsets 32-bit for any song length);
+    // offsets before the song start wrap to huge values and read 0 = the reference's zero history
+    const long tile_first = (long)tile_idx * F512_TILE * HOP_T - (W512 - HOP_T) - HOP_T;  // sample of frame (tile*T - 1)
+    const long base = tile_first > 0 ? tile_first : 0;
+    const uint64_t avail = (sd.n - (uint64_t)base) * 4;
+    const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(pcm + sd.pcm_off + base), 0, (uint32_t)(avail < 0xFFFFFFFFull ? avail : 0xFFFFFFFFull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_win = __builtin_amdgcn_make_buffer_rsrc((void*)hannz, 0, W512 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_tw = __builtin_amdgcn_make_buffer_rsrc((void*)tw512, 0, W512 * 8, 0x00020000);
+
+    FrameMags cur, prev;
+    const bool active = k_begin < (long)sd.n_f;
+    // halo: magnitudes of the previous tempo frame (FFT frame k_begin - 1); zeros before the song starts
+    if (active && k_begin >= 1) {
+        fft512_frame(r_x, k_begin * HOP_T - W512 - base, l, tile, r_win, r_tw, prev);
     } else {
 #pragma unroll
-        for (int e = 0; e < 4; e++) lds.prevmag[4 * lane + e] = 0.0f;
-        if (lane == 0) lds.prevmag[256] = 0.0f;
+        for (int e = 0; e < 16; e++) prev.m[e] = 0.0f;
+        prev.nyq = 0.0f;
     }
-    __builtin_amdgcn_wave_barrier();
 
     for (long k = k_begin; k < k_end; k++) {
-        fft512_frame(x, k, lds, hannz, tw512, m, &nyq);
+        fft512_frame(r_x, (k + 1) * HOP_T - W512 - base, l, tile, r_win, r_tw, cur);
 
         if (k & 1) {  // tempo frame j = (k-1)/2 : SpecFlux over bins 0..256
             float f = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float old = lds.prevmag[4 * lane + e];
-                if (m[e] > old) f += m[e] - old;
-                lds.prevmag[4 * lane + e] = m[e];
+            for (int e = 0; e < 16; e++) {
+                if (cur.m[e] > prev.m[e]) f += cur.m[e] - prev.m[e];
+                prev.m[e] = cur.m[e];
             }
-            if (lane == 0) {
-                const float old = lds.prevmag[256];
-                if (nyq > old) f += nyq - old;
-                lds.prevmag[256] = nyq;
-            }
-            f = wave_sum(f);
+            if (l == 0 && cur.nyq > prev.nyq) f += cur.nyq - prev.nyq;
+            prev.nyq = cur.nyq;
+            f = row16_sum(f);
             const long j = (k - 1) >> 1;
-            if (lane == 0 && j < (long)sd.n_b) flux[sd.b_off + j] = f;
+            if (l == 0 && j < (long)sd.n_b) flux[sd.b_off + j] = f;
         }
 
         if (k < (long)sd.n_t) {
             // the 256-bin vector the reference's timbral path sees: bin 255 := |Re X[256]|
-            if (lane == 63) m[3] = nyq;
-            float sum = 0.0f, wsum = 0.0f, sq[4], sqsum = 0.0f;
+            if (l == 15) cur.m[15] = cur.nyq;
+            float sum = 0.0f, wsum = 0.0f, sqsum = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                sum += m[e];
-                wsum += (float)(4 * lane + e) * m[e];
-                sq[e] = m[e] * m[e];
-                sqsum += sq[e];
+            for (int e = 0; e < 16; e++) {
+                sum += cur.m[e];
+                wsum += (float)(16 * l + e) * cur.m[e];
+                sqsum += cur.m[e] * cur.m[e];
             }
-            const float total = wave_sum(sum);
-            const float wtotal = wave_sum(wsum);
+            const float total = row16_sum(sum);
+            const float wtotal = row16_sum(wsum);
             // spectral_centroid (src/aubio.rs:16-29) then bin_to_freq (:68-71)
             const float cbin = (total == 0.0f) ? 0.0f : wtotal / total;
             const float freq_per_bin = (float)SAMPLE_RATE / (float)W512;
             // spectral_rolloff (src/aubio.rs:36-58): bins consumed until the running energy reaches 95 %
-            const float incl = wave_scan_incl(sqsum);
-            const float cum_total = __shfl(incl, 63, WAVE);
+            const float incl = row16_scan_incl(sqsum);
+            const float cum_total = row16_sum(sqsum);
             float rbin = 0.0f;
             if (cum_total != 0.0f) {
                 const float thr = cum_total * 0.95f;
                 float run = incl - sqsum;
-                uint32_t below = 0;
+                int below = 0;
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    run += sq[e];
-                    below += (run < thr) ? 1u : 0u;
+                for (int e = 0; e < 16; e++) {
+                    run += cur.m[e] * cur.m[e];
+                    below += (run < thr) ? 1 : 0;
                 }
-                const uint32_t c = wave_sum(below);
-                rbin = (float)((c < 256u) ? c + 1u : 256u);
+                const int c = row16_sum(below);
+                rbin = (float)((c < 256) ? c + 1 : 256);
             }
             // geometric_mean (src/utils.rs:101-117): groups of 8 in f64, exponents and mantissas apart
-            double p = ((double)m[0] * (double)m[1]) * ((double)m[2] * (double)m[3]);
-            const double p_hi = __shfl_down(p, 1, WAVE);
-            int expo = 0;
+            int expo = 0, zero = 0;
             double mant = 1.0;
-            int zero = 0;
-            if ((lane & 1) == 0) {
-                double g = p * 3.273390607896142e150;
-                g *= p_hi;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float* c8 = cur.m + 8 * h;
+                double g = ((double)c8[0] * (double)c8[1]) * ((double)c8[2] * (double)c8[3]);
+                g *= 3.273390607896142e150;
+                g *= ((double)c8[4] * (double)c8[5]) * ((double)c8[6] * (double)c8[7]);
                 if (g == 0.0) zero = 1;
                 const uint64_t bits = (uint64_t)__double_as_longlong(g);
-                expo = (int)(bits >> 52);
-                mant = __longlong_as_double((long long)((bits & 0xFFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+                expo += (int)(bits >> 52);
+                mant *= __longlong_as_double((long long)((bits & 0xFFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
             }
-            const int any_zero = __any(zero);
-            const int exps = wave_sum(expo);
-            const double mants = wave_prod(mant);
+            const int any_zero = row16_sum(zero);
+            const int exps = row16_sum(expo);
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) mant *= __shfl_xor(mant, off, 16);
             float flat = 0.0f;
             if (!any_zero) {
-                const float geo = exp2f((log2f((float)mants) + (float)exps) / 256.0f - (1023.0f + 500.0f) / 8.0f);
+                const float geo = exp2f((log2f((float)mant) + (float)exps) / 256.0f - (1023.0f + 500.0f) / 8.0f);
                 if (geo != 0.0f) flat = geo / (total / 256.0f);
             }
-            if (lane == 0) {
+            if (l == 0) {
                 centroid[sd.t_off + k] = freq_per_bin * fmaxf(cbin, 0.0f);
                 rolloff[sd.t_off + k] = freq_per_bin * fmaxf(rbin, 0.0f);
                 flatness[sd.t_off + k] = flat;

@@ -16,52 +16,61 @@ namespace bg {
 
 __device__ __forceinline__ float normalize(float v, float mn, float mx) { return 2.0f * (v - mn) / (mx - mn) - 1.0f; }
 
+// The loops below are sequential by definition (they reproduce the reference's rounding order); the
+// loads are issued 16 at a time so the dependent arithmetic chain never waits on memory.
+constexpr int SEQ_CHUNK = 16;
+
 __device__ float seq_mean(const float* __restrict__ x, uint32_t n) {
     float s = 0.0f;
-    for (uint32_t i = 0; i < n; i++) s += x[i];
+    uint32_t i = 0;
+    for (; i + SEQ_CHUNK <= n; i += SEQ_CHUNK) {
+        float v[SEQ_CHUNK];
+#pragma unroll
+        for (int u = 0; u < SEQ_CHUNK; u++) v[u] = x[i + u];
+#pragma unroll
+        for (int u = 0; u < SEQ_CHUNK; u++) s += v[u];
+    }
+    for (; i < n; i++) s += x[i];
     return s / (float)n;
+}
+
+__device__ __forceinline__ void welford_step(float v, uint32_t i, float& mean, float& sum_sq) {
+    const float count = (float)(i + 1);
+    const float delta = v - mean;
+    mean = mean + delta / count;
+    sum_sq = __fmaf_rn(v - mean, delta, sum_sq);
 }
 
 __device__ float seq_std(const float* __restrict__ x, uint32_t n) {
     float mean = 0.0f, sum_sq = 0.0f;
-    for (uint32_t i = 0; i < n; i++) {
-        const float v = x[i];
-        const float count = (float)(i + 1);
-        const float delta = v - mean;
-        mean = mean + delta / count;
-        sum_sq = __fmaf_rn(v - mean, delta, sum_sq);
+    uint32_t i = 0;
+    for (; i + SEQ_CHUNK <= n; i += SEQ_CHUNK) {
+        float v[SEQ_CHUNK];
+#pragma unroll
+        for (int u = 0; u < SEQ_CHUNK; u++) v[u] = x[i + u];
+#pragma unroll
+        for (int u = 0; u < SEQ_CHUNK; u++) welford_step(v[u], i + u, mean, sum_sq);
     }
+    for (; i < n; i++) welford_step(x[i], i, mean, sum_sq);
     return sqrtf(sum_sq / ((float)n - 0.0f));
 }
 
 // roles: one wavefront each (lane 0 works) so the latency-bound sequential loops of one song overlap;
 // songs run in parallel across workgroups
-enum Role { R_CENT_MEAN = 0, R_CENT_STD, R_ROLL_MEAN, R_ROLL_STD, R_FLAT_MEAN, R_FLAT_STD, R_LOUD, R_ZCR, R_CHROMA, R_COUNT };
+enum Role { R_CENT_MEAN = 0, R_CENT_STD, R_ROLL_MEAN, R_ROLL_STD, R_FLAT_MEAN, R_FLAT_STD, R_LOUD, R_ZCR, R_COUNT };
 
-__global__ __launch_bounds__(64 * 9) void finalize_kernel(const SongDesc* __restrict__ songs,
-                                                      const uint32_t* __restrict__ pfx_ct,
-                                                      const float* __restrict__ centroid,
-                                                      const float* __restrict__ rolloff,
-                                                      const float* __restrict__ flatness,
-                                                      const float* __restrict__ e256,
-                                                      const uint32_t* __restrict__ zc256,
-                                                      const double* __restrict__ chroma_part,
-                                                      const TempoState* __restrict__ tempo,
-                                                      const TuningState* __restrict__ tuning,
-                                                      uint32_t features_version, float* __restrict__ out,
-                                                      int32_t* __restrict__ dbg_tuning,
-                                                      uint32_t* __restrict__ dbg_nbpms) {
-    __shared__ float feat[23];
+// summary[s][0..15]: slots 1..9 = features 1..9 (zcr, centroid, rolloff, flatness, loudness)
+__global__ __launch_bounds__(64 * 8) void summary_kernel(const SongDesc* __restrict__ songs,
+                                                         const float* __restrict__ centroid,
+                                                         const float* __restrict__ rolloff,
+                                                         const float* __restrict__ flatness,
+                                                         const float* __restrict__ e256,
+                                                         const uint32_t* __restrict__ zc256,
+                                                         float* __restrict__ summary) {
     const uint32_t s = blockIdx.x;
     const SongDesc sd = songs[s];
-    const uint32_t d = features_version == 1 ? 20 : 23;
-    float* o = out + (size_t)sd.row * d;
-    const int tid = threadIdx.x;
-    if (!sd.ok) {
-        if (tid < (int)d) o[tid] = __int_as_float(0x7fc00000);  // NaN row; status says why
-        if (tid == 0) { dbg_tuning[sd.row] = -1; dbg_nbpms[sd.row] = 0; }
-        return;
-    }
+    if (!sd.ok) return;
+    float* feat = summary + (size_t)s * 16;
     const float half_sr = (float)SAMPLE_RATE / 2.0f;
     const int role = (lane_id() == 0) ? wave_id() : -1;
     switch (role) {
@@ -82,10 +91,7 @@ __global__ __launch_bounds__(64 * 9) void finalize_kernel(const SongDesc* __rest
                 const uint64_t len = ((uint64_t)(c + 1) * LOUD_W <= sd.n) ? LOUD_W : sd.n - (uint64_t)c * LOUD_W;
                 const float v = en / (float)len;
                 msum += v;
-                const float count = (float)(c + 1);
-                const float delta = v - mean;
-                mean = mean + delta / count;
-                sum_sq = __fmaf_rn(v - mean, delta, sum_sq);
+                welford_step(v, c, mean, sum_sq);
             }
             float mean_value = msum / (float)sd.n_l;
             float std_value = sqrtf(sum_sq / ((float)sd.n_l - 0.0f));
@@ -100,49 +106,76 @@ __global__ __launch_bounds__(64 * 9) void finalize_kernel(const SongDesc* __rest
             uint32_t c = 0;
             for (uint32_t q = 0; q < sd.n_e; q++) c += z[q];
             feat[1] = normalize((float)c / (float)sd.n, 0.0f, 1.0f);
-            feat[0] = tempo[s].tempo;
-            break;
-        }
-        case R_CHROMA: {
-            // chroma_interval_features' time mean (src/chroma.rs:154), tiles summed in order
-            const uint32_t t0 = pfx_ct[s], t1 = pfx_ct[s + 1];
-            double raw[10];
-            for (int t = 0; t < 10; t++) {
-                double acc = 0.0;
-                for (uint32_t k = t0; k < t1; k++) acc += chroma_part[(size_t)k * 10 + t];
-                raw[t] = acc / (double)sd.n_c;
-            }
-            if (features_version == 1) {
-                for (int t = 0; t < 10; t++) feat[10 + t] = 2.0f * ((float)raw[t] - 0.0f) / (0.12f - 0.0f) - 1.0f;
-            } else {
-                double n1 = 0.0, n2 = 0.0;
-                for (int t = 0; t < 6; t++) n1 += raw[t] * raw[t];
-                for (int t = 6; t < 10; t++) n2 += raw[t] * raw[t];
-                n1 = sqrt(n1);
-                n2 = sqrt(n2);
-                if (n1 > 0.0) for (int t = 0; t < 6; t++) raw[t] /= n1;
-                if (n2 > 0.0) for (int t = 6; t < 10; t++) raw[t] /= n2;
-                for (int t = 0; t < 10; t++) feat[10 + t] = 2.0f * ((float)raw[t] - 0.0f) / (1.0f - 0.0f) - 1.0f;
-                feat[20] = fminf(2.0f * ((float)n1 - 0.0f) / (0.25f - 0.0f) - 1.0f, 1.0f);
-                feat[21] = fminf(2.0f * ((float)n2 - 0.0f) / (0.025f - 0.0f) - 1.0f, 1.0f);
-                const double angle = atan2(20.0 * n2, n1 + 1e-12);
-                feat[22] = 2.0f * ((float)angle - 0.0f) / (1.57079632679489661923f - 0.0f) - 1.0f;
-            }
             break;
         }
         default: break;
     }
-    __syncthreads();
-    if (tid < (int)d) o[tid] = feat[tid];
-    if (tid == 0) { dbg_tuning[sd.row] = tuning[s].tuning_idx; dbg_nbpms[sd.row] = tempo[s].n_bpms; }
+}
+
+// one thread per song: chroma summary (ChromaDesc::get_values*), tempo, and the row itself
+__global__ __launch_bounds__(64) void assemble_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs,
+                                                      const uint32_t* __restrict__ pfx_ct,
+                                                      const float* __restrict__ summary,
+                                                      const double* __restrict__ chroma_part,
+                                                      const TempoState* __restrict__ tempo,
+                                                      const TuningState* __restrict__ tuning,
+                                                      uint32_t features_version, float* __restrict__ out,
+                                                      int32_t* __restrict__ dbg_tuning,
+                                                      uint32_t* __restrict__ dbg_nbpms) {
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_songs) return;
+    const SongDesc sd = songs[s];
+    const uint32_t d = features_version == 1 ? 20 : 23;
+    float* o = out + (size_t)sd.row * d;
+    if (!sd.ok) {
+        for (uint32_t k = 0; k < d; k++) o[k] = __int_as_float(0x7fc00000);  // NaN row; status says why
+        dbg_tuning[sd.row] = -1;
+        dbg_nbpms[sd.row] = 0;
+        return;
+    }
+    float feat[23];
+    feat[0] = tempo[s].tempo;
+    for (int k = 1; k < 10; k++) feat[k] = summary[(size_t)s * 16 + k];
+    // chroma_interval_features' time mean (src/chroma.rs:154), tiles summed in order
+    const uint32_t t0 = pfx_ct[s], t1 = pfx_ct[s + 1];
+    double raw[10];
+    for (int t = 0; t < 10; t++) {
+        double acc = 0.0;
+        for (uint32_t k = t0; k < t1; k++) acc += chroma_part[(size_t)k * 10 + t];
+        raw[t] = acc / (double)sd.n_c;
+    }
+    if (features_version == 1) {
+        for (int t = 0; t < 10; t++) feat[10 + t] = 2.0f * ((float)raw[t] - 0.0f) / (0.12f - 0.0f) - 1.0f;
+    } else {
+        double n1 = 0.0, n2 = 0.0;
+        for (int t = 0; t < 6; t++) n1 += raw[t] * raw[t];
+        for (int t = 6; t < 10; t++) n2 += raw[t] * raw[t];
+        n1 = sqrt(n1);
+        n2 = sqrt(n2);
+        if (n1 > 0.0) for (int t = 0; t < 6; t++) raw[t] /= n1;
+        if (n2 > 0.0) for (int t = 6; t < 10; t++) raw[t] /= n2;
+        for (int t = 0; t < 10; t++) feat[10 + t] = 2.0f * ((float)raw[t] - 0.0f) / (1.0f - 0.0f) - 1.0f;
+        feat[20] = fminf(2.0f * ((float)n1 - 0.0f) / (0.25f - 0.0f) - 1.0f, 1.0f);
+        feat[21] = fminf(2.0f * ((float)n2 - 0.0f) / (0.025f - 0.0f) - 1.0f, 1.0f);
+        const double angle = atan2(20.0 * n2, n1 + 1e-12);
+        feat[22] = 2.0f * ((float)angle - 0.0f) / (1.57079632679489661923f - 0.0f) - 1.0f;
+    }
+    for (uint32_t k = 0; k < d; k++) o[k] = feat[k];
+    dbg_tuning[sd.row] = tuning[s].tuning_idx;
+    dbg_nbpms[sd.row] = tempo[s].n_bpms;
+}
+
+void launch_summary(const Batch& b, const Workspace& w, hipStream_t st) {
+    if (b.n_songs == 0) return;
+    hipLaunchKernelGGL(summary_kernel, dim3(b.n_songs), dim3(64 * R_COUNT), 0, st, b.songs, w.centroid, w.rolloff,
+                       w.flatness, w.e256, w.zc256, w.summary);
 }
 
 void launch_finalize(const Batch& b, const Workspace& w, uint32_t features_version, float* d_out, int32_t* dbg_tuning,
                      uint32_t* dbg_nbpms, hipStream_t st) {
     if (b.n_songs == 0) return;
-    hipLaunchKernelGGL(finalize_kernel, dim3(b.n_songs), dim3(64 * R_COUNT), 0, st, b.songs, b.pfx_ct, w.centroid, w.rolloff,
-                       w.flatness, w.e256, w.zc256, w.chroma_part, w.tempo, w.tuning, features_version, d_out, dbg_tuning,
-                       dbg_nbpms);
+    hipLaunchKernelGGL(assemble_kernel, dim3((b.n_songs + 63) / 64), dim3(64), 0, st, b.songs, b.n_songs, b.pfx_ct,
+                       w.summary, w.chroma_part, w.tempo, w.tuning, features_version, d_out, dbg_tuning, dbg_nbpms);
 }
 
 }  // namespace bg

@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void pcm_stats_kernel(const float* __restrict_
     const uint32_t tile = blockIdx.x - pfx_e[s];
     const float* __restrict__ x = pcm + sd.pcm_off;
     const int lane = lane_id(), wave = wave_id();
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
 #pragma unroll
     for (int i = 0; i < PCM_TILE_BLOCKS / 4; i++) {
         const uint32_t q = tile * PCM_TILE_BLOCKS + wave * (PCM_TILE_BLOCKS / 4) + i;
@@ -29,6 +30,21 @@ __global__ __launch_bounds__(256) void pcm_stats_kernel(const float* __restrict_
         uint32_t prev_pos = (x[base > 0 ? base - 1 : 0] > 0.0f) ? 1u : 0u;
         float ss = 0.0f;
         uint32_t zc = 0;
+        if (aligned16 && base + 256 <= sd.n) {  // wave-uniform: one 16-byte load per lane covers the block
+            const float4 v = *reinterpret_cast<const float4*>(x + base + 4 * lane);
+            ss = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            const uint32_t p0 = v.x > 0.0f, p1 = v.y > 0.0f, p2 = v.z > 0.0f, p3 = v.w > 0.0f;
+            uint32_t before = __shfl_up(p3, 1, WAVE);
+            if (lane == 0) before = prev_pos;
+            zc = (p0 != before) + (p1 != p0) + (p2 != p1) + (p3 != p2);
+            ss = wave_sum(ss);
+            zc = wave_sum(zc);
+            if (lane == 0) {
+                e256[sd.e_off + q] = ss;
+                zc256[sd.e_off + q] = zc;
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint64_t idx = base + j * 64 + lane;
