@@ -15,6 +15,7 @@
 //                        followed per frame by the L1 normalisation, exp(15x), normalisation and the
 //                        10 interval templates x 12 rotations (:137-188), summed over the tile.
 #include <float.h>
+#include <stdlib.h>
 
 #include "device_utils.hpp"
 #include "fft_r16.hpp"
@@ -148,15 +149,15 @@ __device__ __forceinline__ uint32_t coarse_bin(double mag) {
 // ------------------------------------------------------------------------------------------------
 constexpr int STFT_FRAMES_PER_WG = STFT_TILE;
 constexpr int LHIST_BINS = 512;  // 16 octaves of 32 coarse bins
-constexpr int EX1_PITCH = 258;   // k1-major rows of 256 (+2): pass-2 reads hit 64 distinct banks
+constexpr int EX1_PITCH = 257;   // k1-major rows of 256 (+1): the 16 lanes of a ds_read2_b64 group tile all 32 banks
 constexpr int EX2_PITCH = 272;   // j1-major rows of 256 (+16): shifts odd rows by 32 banks
 constexpr int STFT_LDS = 16 * EX2_PITCH;  // float2 elements (34 816 B)
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 // 8-byte load through a buffer descriptor: 32-bit lane offset + scalar offset (no 64-bit address VGPRs)
-__device__ __forceinline__ float2 buf_load_f2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+__device__ __forceinline__ f2 buf_load_f2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+    return mk(__uint_as_float(v.x), __uint_as_float(v.y));
 }
 
 __device__ __forceinline__ long reflect_index(long p, long n) {
@@ -166,13 +167,15 @@ __device__ __forceinline__ long reflect_index(long p, long n) {
     return p;
 }
 
+template <int ABL>  // ABL != 0: timing ablations (developer aid, BLISSGPU_ABL), results are wrong
 __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restrict__ pcm,
                                                        const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                        const uint32_t* __restrict__ pfx_c,
                                                        const float* __restrict__ hann,
-                                                       const float2* __restrict__ tw, float* __restrict__ spec,
+                                                       const float2* __restrict__ tw,
+                                                       const float2* __restrict__ tw_p1, float* __restrict__ spec,
                                                        float* __restrict__ frame_max, uint32_t* __restrict__ h1) {
-    __shared__ float2 lds[STFT_LDS];
+    __shared__ f2 lds[STFT_LDS];
     __shared__ float red[4];
     // peaks are first counted in an LDS window of the coarse-magnitude histogram (a frame's peaks lie
     // within [0.1 max, ~max], i.e. ~110 coarse bins) and flushed once per workgroup: global atomics on
@@ -181,6 +184,11 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
     __shared__ uint32_t lhist_base;
     __shared__ uint16_t peak_list[PIP_MAX_PER_FRAME + 2];
     __shared__ uint32_t peak_count;
+    __shared__ f2 tw256[256];  // W_256^(m2*j1) at [16 j1 + m2] (pass-2 twiddles, broadcast reads)
+    {
+        const float2 a = tw[32 * (((threadIdx.x >> 4) * (threadIdx.x & 15)) & 255)];
+        tw256[threadIdx.x] = mk(a.x, a.y);
+    }
     const uint32_t s = find_segment(pfx_c, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
     const uint32_t tile = blockIdx.x - pfx_c[s];
@@ -192,50 +200,78 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
     // descriptors: window table (8192 f32) and twiddle table (8192 float2); wave-uniform
     const __amdgpu_buffer_rsrc_t r_hann = __builtin_amdgcn_make_buffer_rsrc((void*)hann, 0, W8192 * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_tw = __builtin_amdgcn_make_buffer_rsrc((void*)tw, 0, W8192 * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_p1 = __builtin_amdgcn_make_buffer_rsrc((void*)tw_p1, 0, 16 * 256 * 8, 0x00020000);
     const uint32_t t8 = 8u * (uint32_t)t;  // byte offset of (x[2t], x[2t+1]) / (hann[2t], hann[2t+1])
+    // the window values of this thread's 16 complex inputs stay in registers for all frames of the tile
+    f2 win[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; n1++) win[n1] = buf_load_f2(r_hann, t8, 2048u * n1);
     uint32_t* hist = h1 + (size_t)s * H1_BINS;
     for (int i = t; i < LHIST_BINS; i += 256) lhist[i] = 0;
     bool have_base = false;
+    // The magnitudes of a frame are written to HBM one iteration late, AFTER the next frame's loads have
+    // been issued: vmcnt retires in order, so loads issued behind 17 stores would wait for the stores'
+    // HBM round trip at the top of every frame.
+    float pend_lo[8], pend_hi[8], pend_mid = 0.0f;
+    float* pend_row = nullptr;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { pend_lo[j] = 0.0f; pend_hi[j] = 0.0f; }
 
 #pragma unroll 1
     for (int fi = 0; fi < STFT_FRAMES_PER_WG; fi++) {
         const uint32_t f = tile * STFT_FRAMES_PER_WG + fi;
         if (f >= sd.n_c) break;  // uniform
         const long w0 = (long)f * HOP_C - W8192 / 2;
-        float2 v[16];
+        f2 v[16];
         // ---- load + window (reflect only at the song edges) ----
-        if (w0 >= 0 && w0 + W8192 <= n) {
-            const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + w0), 0, W8192 * 4, 0x00020000);
+        if (ABL == 3) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) v[n1] = mk((float)(t + n1 + fi), 1.0f);
+        } else if (w0 >= 0 && w0 + W8192 <= n) {
+            const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(ABL == 4 ? pcm + 4096 : x + w0), 0, W8192 * 4, 0x00020000);
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
-                const float2 w = buf_load_f2(r_hann, t8, 2048u * n1);
-                const float2 xv = buf_load_f2(r_x, t8, 2048u * n1);
-                v[n1] = make_float2(xv.x * w.x, xv.y * w.y);
+                v[n1] = buf_load_f2(r_x, t8, 2048u * n1) * win[n1];
             }
         } else {
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
                 const long p = w0 + 2 * (256 * n1 + t);
-                const float2 w = buf_load_f2(r_hann, t8, 2048u * n1);
-                v[n1] = make_float2(x[reflect_index(p, n)] * w.x, x[reflect_index(p + 1, n)] * w.y);
+                v[n1] = mk(x[reflect_index(p, n)], x[reflect_index(p + 1, n)]) * win[n1];
             }
         }
-        // ---- pass 1: DFT over n1 at n2 = t; twiddle W_4096^(t*k1) ----
+        // pass-1 twiddles W_4096^(t*k1) (lane-contiguous table), issued before the deferred stores
+        f2 twp[16];
+#pragma unroll
+        for (int k1 = 1; k1 < 16; k1++) twp[k1] = ABL == 5 ? mk(0.6f, 0.8f) : buf_load_f2(r_p1, t8, 2048u * k1);
+        if (pend_row != nullptr) {  // uniform: previous frame's magnitudes
+            if (ABL != 7) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    pend_row[t + 256 * j] = pend_lo[j];
+                    pend_row[4096 - (t + 256 * j)] = pend_hi[j];
+                }
+            }
+            if (t == 0) pend_row[2048] = pend_mid;
+            if (t >= 1 && t < CBINS_PAD - 4096) pend_row[4096 + t] = 0.0f;  // zero padding after bin 4096
+        }
+        // ---- pass 1: DFT over n1 at n2 = t ----
         radix16(v);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], buf_load_f2(r_tw, 16u * (uint32_t)t * k1, 0));
+        for (int k1 = 1; k1 < 16; k1++) v[R16(k1)] = cmul_pk(v[R16(k1)], twp[k1]);
 #pragma unroll
-        for (int k1 = 0; k1 < 16; k1++) lds[k1 * EX1_PITCH + t] = v[k1];
+        for (int k1 = 0; k1 < 16; k1++) lds[k1 * EX1_PITCH + t] = v[R16(k1)];
         __syncthreads();
         // ---- pass 2: thread (k1 = lo4, m2 = hi4): DFT over m1; twiddle W_256^(m2*j1) ----
 #pragma unroll
-        for (int m1 = 0; m1 < 16; m1++) v[m1] = lds[lo4 * EX1_PITCH + 16 * m1 + hi4];
+        for (int m1 = 0; m1 < 16; m1++) v[m1] = ABL == 8 ? lds[t + 256 * m1] : lds[lo4 * EX1_PITCH + 16 * m1 + hi4];
         radix16(v);
 #pragma unroll
-        for (int j1 = 1; j1 < 16; j1++) v[j1] = cmul(v[j1], buf_load_f2(r_tw, 256u * (uint32_t)hi4 * j1, 0));
+        for (int j1 = 1; j1 < 16; j1++) v[R16(j1)] = cmul_pk(v[R16(j1)], tw256[16 * j1 + hi4]);  // W_256^(m2*j1)
         __syncthreads();
 #pragma unroll
-        for (int j1 = 0; j1 < 16; j1++) lds[j1 * EX2_PITCH + t] = v[j1];  // = j1*272 + m2*16 + k1
+        for (int j1 = 0; j1 < 16; j1++) lds[j1 * EX2_PITCH + t] = v[R16(j1)];  // = j1*272 + m2*16 + k1
         __syncthreads();
         // ---- pass 3: thread (k1 = lo4, j1 = hi4): DFT over m2 -> Z[t + 256*j2] ----
 #pragma unroll
@@ -243,34 +279,40 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
         radix16(v);
         __syncthreads();
 #pragma unroll
-        for (int j2 = 0; j2 < 16; j2++) lds[t + 256 * j2] = v[j2];
+        for (int j2 = 0; j2 < 16; j2++) lds[t + 256 * j2] = v[R16(j2)];
         __syncthreads();
-        // ---- real-input split + magnitude (src/utils.rs:60), bins k = t + 256*j ----
-        float m[16];
+        // ---- real-input split + magnitude (src/utils.rs:60).  Z[k] and Z[4096-k] yield X[k] AND X[4096-k]:
+        // thread t pairs its bins k = t + 256 j, j < 8, with their mirrors (k = 0 pairs DC with Nyquist);
+        // bin 2048 (its own mirror) is done by thread 0 ----
+        float m_lo[8], m_hi[8], m_mid = 0.0f;
         float mx = 0.0f;
-        const float2 z0 = lds[0];
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < 8; j++) {
             const int k = t + 256 * j;
-            if (k == 0) {
-                m[j] = fabsf(z0.x + z0.y);
-            } else {
-                const float2 X = real_split(v[j], lds[4096 - k], buf_load_f2(r_tw, t8, 2048u * j));
-                m[j] = sqrtf(X.x * X.x + X.y * X.y);
-            }
-            mx = fmaxf(mx, m[j]);
+            float sq_k, sq_m;
+            if (ABL == 2) { sq_k = v[R16(j)].x; sq_m = v[R16(j)].y; }
+            else split_pair_sq(v[R16(j)], lds[(4096 - k) & 4095], ABL == 6 ? mk(0.6f, 0.8f) : buf_load_f2(r_tw, t8, 2048u * j), sq_k, sq_m);
+            m_lo[j] = mag_from_sq4(sq_k);
+            m_hi[j] = mag_from_sq4(sq_m);
+            mx = fmaxf(mx, fmaxf(m_lo[j], m_hi[j]));
         }
-        const float nyq = fabsf(z0.x - z0.y);
-        mx = fmaxf(mx, nyq);
-        float* row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
+        if (t == 0) {
+            m_mid = mag_from_sq4(split_one_sq(v[R16(8)], v[R16(8)], mk(0.0f, -1.0f)));  // k = 2048: W_8192^2048 = -i
+            mx = fmaxf(mx, m_mid);
+        }
+        pend_row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
 #pragma unroll
-        for (int j = 0; j < 16; j++) row[t + 256 * j] = m[j];
-        if (t < CBINS_PAD - 4096) row[4096 + t] = (t == 0) ? nyq : 0.0f;  // bin 4096 + zero padding
+        for (int j = 0; j < 8; j++) { pend_lo[j] = m_lo[j]; pend_hi[j] = m_hi[j]; }
+        pend_mid = m_mid;
         mx = wave_max(mx);
         __syncthreads();  // all split reads of lds are done
         float* mags = reinterpret_cast<float*>(lds);
 #pragma unroll
-        for (int j = 0; j < 16; j++) mags[t + 256 * j] = m[j];
+        for (int j = 0; j < 8; j++) {
+            mags[t + 256 * j] = m_lo[j];
+            mags[4096 - (t + 256 * j)] = m_hi[j];
+        }
+        if (t == 0) mags[2048] = m_mid;
         if (lane_id() == 0) red[wave_id()] = mx;
         __syncthreads();
         mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -289,6 +331,7 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
         const double ref = 0.1 * (double)mx;
         if (t == 0) peak_count = 0;
         __syncthreads();
+        if (ABL != 1)
         for (int c = PIP_LO + t; c < PIP_LO + 6 * 256; c += 256) {  // uniform trip count (ballots inside)
             const bool pk = (c <= PIP_HI) && pip_is_peak(mags[c - 1], mags[c], mags[c + 1], ref);
             wave_append(pk, c, peak_list, &peak_count);
@@ -306,6 +349,17 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
         }
         __syncthreads();  // mags (lds) is reused by the next frame
     }
+    if (pend_row != nullptr) {
+        if (ABL != 7) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                pend_row[t + 256 * j] = pend_lo[j];
+                pend_row[4096 - (t + 256 * j)] = pend_hi[j];
+            }
+        }
+        if (t == 0) pend_row[2048] = pend_mid;
+        if (t >= 1 && t < CBINS_PAD - 4096) pend_row[4096 + t] = 0.0f;
+    }
     if (have_base) {
         const uint32_t lbase = lhist_base;
         for (int i = t; i < LHIST_BINS; i += 256) {
@@ -317,8 +371,19 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
 
 void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.tiles_c == 0) return;
-    hipLaunchKernelGGL(stft8192_kernel, dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_c,
-                       t.hann8192, t.tw8192, w.spec, w.frame_max, w.h1);
+    static const int abl = getenv("BLISSGPU_ABL") ? atoi(getenv("BLISSGPU_ABL")) : 0;
+#define LAUNCH_STFT(A) hipLaunchKernelGGL(stft8192_kernel<A>, dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, \
+                                          b.pfx_c, t.hann8192, t.tw8192, t.tw_p1, w.spec, w.frame_max, w.h1)
+    if (abl == 1) LAUNCH_STFT(1);
+    else if (abl == 2) LAUNCH_STFT(2);
+    else if (abl == 3) LAUNCH_STFT(3);
+    else if (abl == 4) LAUNCH_STFT(4);
+    else if (abl == 5) LAUNCH_STFT(5);
+    else if (abl == 6) LAUNCH_STFT(6);
+    else if (abl == 7) LAUNCH_STFT(7);
+    else if (abl == 8) LAUNCH_STFT(8);
+    else LAUNCH_STFT(0);
+#undef LAUNCH_STFT
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -18,6 +18,8 @@
 // CONSECUTIVE bins 16l..16l+15 (needed by the rolloff prefix sum) and with Z[256-k] for the real-input
 // split.  Reductions stay inside the 16-lane row (DPP).  A group walks FRAMES_PER_GROUP consecutive
 // frames so the previous tempo frame's magnitudes stay in registers (one halo FFT per group).
+#include <stdlib.h>
+
 #include "device_utils.hpp"
 #include "fft_r16.hpp"
 #include "internal.hpp"
@@ -29,9 +31,9 @@ constexpr int FRAMES_PER_GROUP = F512_TILE / GROUPS_PER_WG;
 constexpr int GRP_PITCH = 272;  // float2 per group tile: 16 rows of 17, and == 128 B (mod 256 B) between groups
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float2 buf_load_f2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+__device__ __forceinline__ f2 buf_load_f2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+    return mk(__uint_as_float(v.x), __uint_as_float(v.y));
 }
 
 // ---- reductions across the 16 lanes of a DPP row ----
@@ -66,72 +68,92 @@ struct FrameMags {
 };
 
 // 257 magnitudes of FFT frame k: lane l of the group gets bins 16l..16l+15
-__device__ __forceinline__ void fft512_frame(__amdgpu_buffer_rsrc_t r_x, long rel_start, int l, float2* tile,
-                                             __amdgpu_buffer_rsrc_t r_win, __amdgpu_buffer_rsrc_t r_tw,
-                                             FrameMags& out) {
-    float2 v[16];
+// constant tables staged once per workgroup in LDS (broadcast reads, no VMEM traffic per frame)
+struct Tables512 {
+    f2 win[256];    // (hannz[2n], hannz[2n+1]), n = 16 n1 + l
+    f2 tw256[256];  // W_256^(l*k1) at [16 k1 + l]
+    f2 tw512[256];  // W_512^(16 l + e) at [16 e + l]: lane-contiguous (a [16 l + e] layout is a 16-way bank conflict)
+};
+
+template <int ABL>
+__device__ __forceinline__ void fft512_frame(__amdgpu_buffer_rsrc_t r_x, long rel_start, int l, f2* tile,
+                                             const Tables512* tabs, FrameMags& out) {
+    f2 v[16];
     // z[16 n1 + l] = (x[s + 32 n1 + 2l], x[s + 32 n1 + 2l + 1]); samples before the song start are 0
     // (the reference's zero-initialised sliding buffer); s is a multiple of 128, so pairs never straddle 0
-    const uint32_t loff = 8u * (uint32_t)l;
-    if (rel_start >= 0) {
+    if (ABL == 3) {
+#pragma unroll
+        for (int n1 = 0; n1 < 16; n1++) v[n1] = mk((float)(l + n1), 1.0f) * tabs->win[16 * n1 + l];
+    } else if (rel_start >= 0) {
         const uint32_t xoff = (uint32_t)((rel_start + 2 * l) * 4);
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1++) {
-            const float2 xv = buf_load_f2(r_x, xoff, 128u * n1);
-            const float2 w = buf_load_f2(r_win, loff, 128u * n1);
-            v[n1] = make_float2(xv.x * w.x, xv.y * w.y);
+            v[n1] = buf_load_f2(r_x, xoff, 128u * n1) * tabs->win[16 * n1 + l];
         }
     } else {
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1++) {
             const long idx = rel_start + 32 * n1 + 2 * l;
-            float2 xv = make_float2(0.0f, 0.0f);
+            f2 xv = mk(0.0f, 0.0f);
             if (idx >= 0) xv = buf_load_f2(r_x, (uint32_t)(idx * 4), 0);
-            const float2 w = buf_load_f2(r_win, loff, 128u * n1);
-            v[n1] = make_float2(xv.x * w.x, xv.y * w.y);
+            v[n1] = xv * tabs->win[16 * n1 + l];
         }
     }
-    radix16(v);  // over n1 -> A[k1]
+    radix16(v);  // over n1 -> A[k1] at v[R16(k1)]
 #pragma unroll
-    for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], buf_load_f2(r_tw, 16u * (uint32_t)(l * k1), 0));  // W_256^(l*k1)
+    for (int k1 = 1; k1 < 16; k1++) v[R16(k1)] = cmul_pk(v[R16(k1)], tabs->tw256[16 * k1 + l]);  // W_256^(l*k1)
 #pragma unroll
-    for (int k1 = 0; k1 < 16; k1++) tile[k1 * 17 + l] = v[k1];
+    for (int k1 = 0; k1 < 16; k1++) tile[k1 * 17 + l] = v[R16(k1)];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int n2 = 0; n2 < 16; n2++) v[n2] = tile[l * 17 + n2];
     __builtin_amdgcn_wave_barrier();
-    radix16(v);  // over n2 -> Z[l + 16 k2]
+    if (ABL != 4) radix16(v);  // over n2 -> Z[l + 16 k2] at v[R16(k2)]
 #pragma unroll
-    for (int k2 = 0; k2 < 16; k2++) tile[k2 * 17 + l] = v[k2];  // Z[k] at k + (k >> 4)
+    for (int k2 = 0; k2 < 16; k2++) tile[k2 * 17 + l] = v[R16(k2)];  // Z[k] at k + (k >> 4)
     __builtin_amdgcn_wave_barrier();
-    const float2 z0 = tile[0];
+    const f2 z0 = tile[0];
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-        const float2 zk = tile[l * 17 + e];
+        const f2 zk = tile[l * 17 + e];
         // Z[256 - k], k = 16 l + e  (k = 0 pairs with itself)
         const int mi = (e == 0) ? ((l == 0) ? 0 : 17 * (16 - l)) : (17 * (15 - l) + 16 - e);
-        const float2 zm = tile[mi];
-        const float2 X = real_split(zk, zm, buf_load_f2(r_tw, 128u * (uint32_t)l, 8u * e));  // W_512^k = tw512[k]
-        out.m[e] = sqrtf(X.x * X.x + X.y * X.y);
+        const f2 zm = tile[mi];
+        if (ABL == 2) out.m[e] = zk.x + zm.y;
+        else if (ABL == 5) out.m[e] = 0.5f * split_one_sq(zk, zm, tabs->tw512[16 * e + l]);
+        else if (ABL == 6) out.m[e] = mag_from_sq4(split_one_sq(zk, zm, mk(0.6f, 0.8f)));
+        else if (ABL == 7) out.m[e] = mag_from_sq4(split_one_sq(zk, zk, tabs->tw512[16 * e + l]));
+        else out.m[e] = mag_from_sq4(split_one_sq(zk, zm, tabs->tw512[16 * e + l]));  // W_512^k, k = 16 l + e
     }
     if (l == 0) out.m[0] = fabsf(z0.x + z0.y);
     out.nyq = fabsf(z0.x - z0.y);
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict__ pcm,
+template <int ABL>  // ABL != 0: timing ablations (developer aid, BLISSGPU_ABL512), results are wrong
+__global__ __launch_bounds__(256, 4) void fft512_kernel(const float* __restrict__ pcm,
                                                         const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                         const uint32_t* __restrict__ pfx_f,
                                                         const float* __restrict__ hannz,
                                                         const float2* __restrict__ tw512,
                                                         float* __restrict__ centroid, float* __restrict__ rolloff,
                                                         float* __restrict__ flatness, float* __restrict__ flux) {
-    __shared__ float2 lds[GROUPS_PER_WG * GRP_PITCH];
+    __shared__ f2 lds[GROUPS_PER_WG * GRP_PITCH];
+    __shared__ Tables512 tabs_s;
+    {
+        const int t = threadIdx.x;  // t = 16 a + b
+        const float2 a = tw512[2 * (((t >> 4) * (t & 15)) & 255)], b = tw512[16 * (t & 15) + (t >> 4)];
+        tabs_s.win[t] = mk(hannz[2 * t], hannz[2 * t + 1]);
+        tabs_s.tw256[t] = mk(a.x, a.y);  // W_256^(k1*l) = W_512^(2 k1 l)
+        tabs_s.tw512[t] = mk(b.x, b.y);
+    }
+    __syncthreads();
+    const Tables512* tabs = &tabs_s;
     const uint32_t s = find_segment(pfx_f, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
     const uint32_t tile_idx = blockIdx.x - pfx_f[s];
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
-    float2* tile = lds + grp * GRP_PITCH;
+    f2* tile = lds + grp * GRP_PITCH;
 
     const long k_begin = (long)tile_idx * F512_TILE + (long)grp * FRAMES_PER_GROUP;  // even
     const long k_end = (k_begin + FRAMES_PER_GROUP < (long)sd.n_f) ? k_begin + FRAMES_PER_GROUP : (long)sd.n_f;
@@ -143,14 +165,12 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
     const uint64_t avail = (sd.n - (uint64_t)base) * 4;
     const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(pcm + sd.pcm_off + base), 0, (uint32_t)(avail < 0xFFFFFFFFull ? avail : 0xFFFFFFFFull), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_win = __builtin_amdgcn_make_buffer_rsrc((void*)hannz, 0, W512 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_tw = __builtin_amdgcn_make_buffer_rsrc((void*)tw512, 0, W512 * 8, 0x00020000);
 
     FrameMags cur, prev;
     const bool active = k_begin < (long)sd.n_f;
     // halo: magnitudes of the previous tempo frame (FFT frame k_begin - 1); zeros before the song starts
     if (active && k_begin >= 1) {
-        fft512_frame(r_x, k_begin * HOP_T - W512 - base, l, tile, r_win, r_tw, prev);
+        fft512_frame<ABL>(r_x, k_begin * HOP_T - W512 - base, l, tile, tabs, prev);
     } else {
 #pragma unroll
         for (int e = 0; e < 16; e++) prev.m[e] = 0.0f;
@@ -158,7 +178,7 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
     }
 
     for (long k = k_begin; k < k_end; k++) {
-        fft512_frame(r_x, (k + 1) * HOP_T - W512 - base, l, tile, r_win, r_tw, cur);
+        fft512_frame<ABL>(r_x, (k + 1) * HOP_T - W512 - base, l, tile, tabs, cur);
 
         if (k & 1) {  // tempo frame j = (k-1)/2 : SpecFlux over bins 0..256
             float f = 0.0f;
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
             if (l == 0 && j < (long)sd.n_b) flux[sd.b_off + j] = f;
         }
 
-        if (k < (long)sd.n_t) {
+        if (ABL != 1 && k < (long)sd.n_t) {
             // the 256-bin vector the reference's timbral path sees: bin 255 := |Re X[256]|
             if (l == 15) cur.m[15] = cur.nyq;
             float sum = 0.0f, wsum = 0.0f, sqsum = 0.0f;
@@ -239,8 +259,18 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
 
 void launch_fft512(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.tiles_f == 0) return;
-    hipLaunchKernelGGL(fft512_kernel, dim3(b.tiles_f), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_f,
-                       t.hannz512, t.tw512, w.centroid, w.rolloff, w.flatness, w.flux);
+    static const int abl = getenv("BLISSGPU_ABL512") ? atoi(getenv("BLISSGPU_ABL512")) : 0;
+#define LAUNCH_F512(A) hipLaunchKernelGGL(fft512_kernel<A>, dim3(b.tiles_f), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, \
+                                          b.pfx_f, t.hannz512, t.tw512, w.centroid, w.rolloff, w.flatness, w.flux)
+    if (abl == 1) LAUNCH_F512(1);
+    else if (abl == 2) LAUNCH_F512(2);
+    else if (abl == 3) LAUNCH_F512(3);
+    else if (abl == 4) LAUNCH_F512(4);
+    else if (abl == 5) LAUNCH_F512(5);
+    else if (abl == 6) LAUNCH_F512(6);
+    else if (abl == 7) LAUNCH_F512(7);
+    else LAUNCH_F512(0);
+#undef LAUNCH_F512
 }
 
 }  // namespace bg
