@@ -64,6 +64,7 @@ struct blissgpu_ctx {
     hipStream_t aux_stream = nullptr;  // tempo / timbral / loudness chain, joined before the assembly
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool serial = false;               // BLISSGPU_SERIAL=1: single stream (clean per-kernel timings)
+    bool full_overlap = false;         // BLISSGPU_OVERLAP=2: the two FFT kernels also run concurrently
     uint64_t ws_limit = 96ull << 30;
     // tables
     float2 *tw8192 = nullptr, *tw512 = nullptr, *tw_p1 = nullptr;
@@ -207,7 +208,7 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
     const uint32_t ns = (uint32_t)songs.size();
     if (ns == 0) return BLISSGPU_OK;
     // ---- offsets + tile prefixes ----
-    std::vector<uint32_t> pfx_e(ns + 1, 0), pfx_f(ns + 1, 0), pfx_c(ns + 1, 0), pfx_ct(ns + 1, 0);
+    std::vector<uint32_t> pfx_e(ns + 1, 0), pfx_f(ns + 1, 0), pfx_c(ns + 1, 0), pfx_ct(ns + 1, 0), pfx_cw(ns + 1, 0);
     uint64_t tot_t = 0, tot_b = 0, tot_c = 0, tot_e = 0, tot_cand = 0;
     uint32_t max_nb = 0, max_nt = 0, max_runs = 1;
     for (uint32_t i = 0; i < ns; i++) {
@@ -224,9 +225,10 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
         pfx_f[i + 1] = pfx_f[i] + (d.ok ? (d.n_f + F512_TILE - 1) / F512_TILE : 0);
         pfx_c[i + 1] = pfx_c[i] + (d.ok ? (d.n_c + STFT_TILE - 1) / STFT_TILE : 0);
         pfx_ct[i + 1] = pfx_ct[i] + (d.ok ? (d.n_c + CH_TILE - 1) / CH_TILE : 0);
+        pfx_cw[i + 1] = pfx_cw[i] + (d.ok ? (d.n_c + 4 * CH_TILE - 1) / (4 * CH_TILE) : 0);
     }
     // ---- descriptors to the device (pinned staging, one async copy) ----
-    const size_t desc_bytes = align_up(ns * sizeof(SongDesc), 256) + 4 * align_up((ns + 1) * 4, 256);
+    const size_t desc_bytes = align_up(ns * sizeof(SongDesc), 256) + 5 * align_up((ns + 1) * 4, 256);
     int rc = c->desc.ensure(desc_bytes);
     if (rc) return rc;
     if (desc_bytes > c->h_desc_cap) {
@@ -243,6 +245,7 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
     const size_t o_f = o; memcpy(c->h_desc + o, pfx_f.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
     const size_t o_c = o; memcpy(c->h_desc + o, pfx_c.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
     const size_t o_ct = o; memcpy(c->h_desc + o, pfx_ct.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
+    const size_t o_cw = o; memcpy(c->h_desc + o, pfx_cw.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
     HIP_TRY(hipMemcpyAsync(c->desc.p, c->h_desc, o, hipMemcpyHostToDevice, c->stream));
 
     Batch b{};
@@ -253,7 +256,8 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
     b.pfx_f = reinterpret_cast<const uint32_t*>(c->desc.p + o_f);
     b.pfx_c = reinterpret_cast<const uint32_t*>(c->desc.p + o_c);
     b.pfx_ct = reinterpret_cast<const uint32_t*>(c->desc.p + o_ct);
-    b.tiles_e = pfx_e[ns]; b.tiles_f = pfx_f[ns]; b.tiles_c = pfx_c[ns]; b.tiles_ct = pfx_ct[ns];
+    b.pfx_cw = reinterpret_cast<const uint32_t*>(c->desc.p + o_cw);
+    b.tiles_e = pfx_e[ns]; b.tiles_f = pfx_f[ns]; b.tiles_c = pfx_c[ns]; b.tiles_ct = pfx_ct[ns]; b.tiles_cw = pfx_cw[ns];
     b.total_b = tot_b; b.max_nb = max_nb; b.max_nt = max_nt;
 
     // ---- carve the workspace ----
@@ -299,16 +303,28 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
     // tempo / timbral chains (one workgroup per song: sequential beat tracker, sequential summaries)
     // run beside the chroma chain on the aux stream and are joined before the feature rows are written.
     hipStream_t st = c->stream, sb = c->serial ? c->stream : c->aux_stream;
-    { Prof p(c, K_PCM_STATS); launch_pcm_stats(b, w, st); }
-    { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st); }
-    { Prof p(c, K_ONSET); launch_onset(b, w, st); }
-    if (!c->serial) {
+    if (c->full_overlap && !c->serial) {
+        // whole tempo/timbral chain beside the chroma chain
         HIP_TRY(hipEventRecord(c->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(sb, c->ev_fork, 0));
+        { Prof p(c, K_PCM_STATS, sb); launch_pcm_stats(b, w, sb); }
+        { Prof p(c, K_FFT512, sb); launch_fft512(b, w, c->tables, sb); }
+        { Prof p(c, K_ONSET, sb); launch_onset(b, w, sb); }
+        { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
+        { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
+        HIP_TRY(hipEventRecord(c->ev_join, sb));
+    } else {
+        { Prof p(c, K_PCM_STATS); launch_pcm_stats(b, w, st); }
+        { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st); }
+        { Prof p(c, K_ONSET); launch_onset(b, w, st); }
+        if (!c->serial) {
+            HIP_TRY(hipEventRecord(c->ev_fork, st));
+            HIP_TRY(hipStreamWaitEvent(sb, c->ev_fork, 0));
+        }
+        { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
+        { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
+        if (!c->serial) HIP_TRY(hipEventRecord(c->ev_join, sb));
     }
-    { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
-    { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
-    if (!c->serial) HIP_TRY(hipEventRecord(c->ev_join, sb));
 
     HIP_TRY(hipMemsetAsync(w.h1, 0, (size_t)ns * H1_BINS * 4, st));
     HIP_TRY(hipMemsetAsync(w.hist100, 0, (size_t)ns * N_TUNING * 4, st));
@@ -380,6 +396,7 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (se != hipSuccess) { blissgpu_ctx_destroy(c); return fail(BLISSGPU_ERR_HIP, "aux stream/events", hipGetErrorString(se)); }
     if (const char* e = getenv("BLISSGPU_SERIAL")) c->serial = (e[0] == '1');
+    if (const char* e = getenv("BLISSGPU_OVERLAP")) c->full_overlap = (e[0] == '2');
     int rc = build_tables(c);
     if (rc) { blissgpu_ctx_destroy(c); return rc; }
     *out = c;

@@ -137,8 +137,9 @@ struct Batch {
     const uint32_t* pfx_e;    // pcm-stats tiles
     const uint32_t* pfx_f;    // fft512 tiles
     const uint32_t* pfx_c;    // STFT tiles (STFT_TILE chroma frames each)
-    const uint32_t* pfx_ct;   // chroma contraction tiles
-    uint32_t tiles_e, tiles_f, tiles_c, tiles_ct;
+    const uint32_t* pfx_ct;   // 64-frame chroma tiles (tuning pass 2 workgroups, chroma_part slots)
+    const uint32_t* pfx_cw;   // chroma contraction workgroups (4 tiles of 64 frames each)
+    uint32_t tiles_e, tiles_f, tiles_c, tiles_ct, tiles_cw;
     uint64_t total_b;         // tempo frames in the batch
     uint32_t max_nb;          // longest song's tempo-frame count
     uint32_t max_nt;          // longest song's timbral-frame count

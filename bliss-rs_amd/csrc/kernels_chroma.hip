@@ -217,30 +217,36 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 8; j++) { pend_lo[j] = 0.0f; pend_hi[j] = 0.0f; }
 
-#pragma unroll 1
-    for (int fi = 0; fi < STFT_FRAMES_PER_WG; fi++) {
-        const uint32_t f = tile * STFT_FRAMES_PER_WG + fi;
-        if (f >= sd.n_c) break;  // uniform
+    // raw samples of one frame: z[256*n1 + t] = (x[w0 + 2n], x[w0 + 2n + 1]), reflect only at the song edges
+    auto load_frame = [&](uint32_t f, f2 (&xr)[16]) {
         const long w0 = (long)f * HOP_C - W8192 / 2;
-        f2 v[16];
-        // ---- load + window (reflect only at the song edges) ----
         if (ABL == 3) {
 #pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) v[n1] = mk((float)(t + n1 + fi), 1.0f);
+            for (int n1 = 0; n1 < 16; n1++) xr[n1] = mk((float)(t + n1 + (int)f), 1.0f);
         } else if (w0 >= 0 && w0 + W8192 <= n) {
             const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(ABL == 4 ? pcm + 4096 : x + w0), 0, W8192 * 4, 0x00020000);
 #pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) {
-                v[n1] = buf_load_f2(r_x, t8, 2048u * n1) * win[n1];
-            }
+            for (int n1 = 0; n1 < 16; n1++) xr[n1] = buf_load_f2(r_x, t8, 2048u * n1);
         } else {
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
                 const long p = w0 + 2 * (256 * n1 + t);
-                v[n1] = mk(x[reflect_index(p, n)], x[reflect_index(p + 1, n)]) * win[n1];
+                xr[n1] = mk(x[reflect_index(p, n)], x[reflect_index(p + 1, n)]);
             }
         }
+    };
+
+    // The next frame's samples are requested as soon as the current frame's registers are free (after the
+    // split), so their HBM/L2 latency overlaps the peak-picking phase instead of stalling the next frame.
+    f2 v[16];
+    if (tile * STFT_FRAMES_PER_WG < sd.n_c) load_frame(tile * STFT_FRAMES_PER_WG, v);
+#pragma unroll 1
+    for (int fi = 0; fi < STFT_FRAMES_PER_WG; fi++) {
+        const uint32_t f = tile * STFT_FRAMES_PER_WG + fi;
+        if (f >= sd.n_c) break;  // uniform
+#pragma unroll
+        for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window (src/utils.rs:37-39, :49)
         // pass-1 twiddles W_4096^(t*k1) (lane-contiguous table), issued before the deferred stores
         f2 twp[16];
 #pragma unroll
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 8; j++) { pend_lo[j] = m_lo[j]; pend_hi[j] = m_hi[j]; }
         pend_mid = m_mid;
+        if (fi + 1 < STFT_FRAMES_PER_WG && f + 1 < sd.n_c) load_frame(f + 1, v);  // uniform
         mx = wave_max(mx);
         __syncthreads();  // all split reads of lds are done
         float* mags = reinterpret_cast<float*>(lds);
@@ -627,51 +634,64 @@ __device__ __forceinline__ double interval_feature(const double (&c)[12]) {
     return acc;
 }
 
+// One wavefront owns one 64-frame tile (= one chroma_part slot): four 16-frame MFMA sub-tiles share every
+// filter (A) fragment, so the L2-resident filter bank is read once per 64 frames instead of once per 16.
 __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs,
+                                                     const uint32_t* __restrict__ pfx_cw,
                                                      const uint32_t* __restrict__ pfx_ct,
                                                      const float* __restrict__ spec,
                                                      const double* __restrict__ bank,
                                                      const TuningState* __restrict__ tuning,
                                                      double* __restrict__ chroma_part) {
     __shared__ double tile_c[4][16][13];
-    __shared__ double part[4][10];
-    const uint32_t s = find_segment(pfx_ct, n_songs, blockIdx.x);
+    const uint32_t s = find_segment(pfx_cw, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
-    const uint32_t tile = blockIdx.x - pfx_ct[s];
     const int lane = lane_id(), wave = wave_id();
+    const uint32_t tile64 = (blockIdx.x - pfx_cw[s]) * 4 + wave;   // 64-frame tile of this wave
+    const uint32_t n_tiles = pfx_ct[s + 1] - pfx_ct[s];
+    if (tile64 >= n_tiles) return;  // wave-uniform; no workgroup barriers below
     const int i16 = lane & 15, g = lane >> 4;
     const int tidx = tuning[s].tuning_idx;
     const int slot = (tidx < 0) ? N_TUNING : tidx;
+    const uint32_t f0 = tile64 * CH_TILE;
 
-    const uint32_t f0 = tile * CH_TILE + wave * 16;
+    const double* __restrict__ arow = bank + ((size_t)slot * BANK_ROWS + i16) * CBINS_PAD + 4 * g;
+    const float* brow[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t fj = f0 + 16 * q + i16;
+        if (fj >= sd.n_c) fj = sd.n_c - 1;  // clamped rows are computed and discarded
+        brow[q] = spec + (sd.c_off + fj) * (size_t)CBINS_PAD + 4 * g;
+    }
+    // two independent accumulator chains per sub-tile so consecutive MFMAs do not wait on each other
+    double4_t acc[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { acc[q][0] = double4_t{0.0, 0.0, 0.0, 0.0}; acc[q][1] = double4_t{0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll 2
+    for (int st = 0; st < CBINS_PAD / 16; st++) {
+        const double4_t a = *reinterpret_cast<const double4_t*>(arow + 16 * st);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 b = *reinterpret_cast<const float4*>(brow[q] + 16 * st);
+            const double b0 = (double)b.x * (double)b.x, b1 = (double)b.y * (double)b.y;
+            const double b2 = (double)b.z * (double)b.z, b3 = (double)b.w * (double)b.w;
+            acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0, acc[q][0], 0, 0, 0);
+            acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b1, acc[q][1], 0, 0, 0);
+            acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.z, b2, acc[q][0], 0, 0, 0);
+            acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.w, b3, acc[q][1], 0, 0, 0);
+        }
+    }
     double feat[10];
 #pragma unroll
     for (int t = 0; t < 10; t++) feat[t] = 0.0;
-
-    if (f0 < sd.n_c) {  // wave-uniform
-        uint32_t fj = f0 + i16;
-        if (fj >= sd.n_c) fj = sd.n_c - 1;
-        const double* __restrict__ arow = bank + ((size_t)slot * BANK_ROWS + i16) * CBINS_PAD + 4 * g;
-        const float* __restrict__ brow = spec + (sd.c_off + fj) * (size_t)CBINS_PAD + 4 * g;
-        // two independent accumulator chains so consecutive MFMAs do not wait on each other
-        double4_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-        for (int st = 0; st < CBINS_PAD / 16; st++) {
-            const double4_t a = *reinterpret_cast<const double4_t*>(arow + 16 * st);
-            const float4 b = *reinterpret_cast<const float4*>(brow + 16 * st);
-            const double b0 = (double)b.x * (double)b.x, b1 = (double)b.y * (double)b.y;
-            const double b2 = (double)b.z * (double)b.z, b3 = (double)b.w * (double)b.w;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b1, acc2, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.z, b2, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.w, b3, acc2, 0, 0, 0);
-        }
-        acc += acc2;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const double4_t cacc = acc[q][0] + acc[q][1];
         // C[row = g + 4r][col = i16]: rows are chroma classes, columns are frames
 #pragma unroll
-        for (int r = 0; r < 3; r++) tile_c[wave][i16][g + 4 * r] = acc[r];
+        for (int r = 0; r < 3; r++) tile_c[wave][i16][g + 4 * r] = cacc[r];
         __builtin_amdgcn_wave_barrier();
-        if (lane < 16 && f0 + lane < sd.n_c) {
+        if (lane < 16 && f0 + 16 * q + lane < sd.n_c) {
             double c[12], sum = 0.0;
 #pragma unroll
             for (int k = 0; k < 12; k++) { c[k] = tile_c[wave][lane][k]; sum += fabs(c[k]); }
@@ -682,31 +702,27 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
             if (esum < 0.0001) esum = 1.0;         // normalize_feature_sequence (:177-188)
 #pragma unroll
             for (int k = 0; k < 12; k++) c[k] /= esum;
-            feat[0] = interval_feature<0>(c); feat[1] = interval_feature<1>(c);
-            feat[2] = interval_feature<2>(c); feat[3] = interval_feature<3>(c);
-            feat[4] = interval_feature<4>(c); feat[5] = interval_feature<5>(c);
-            feat[6] = interval_feature<6>(c); feat[7] = interval_feature<7>(c);
-            feat[8] = interval_feature<8>(c); feat[9] = interval_feature<9>(c);
+            feat[0] += interval_feature<0>(c); feat[1] += interval_feature<1>(c);
+            feat[2] += interval_feature<2>(c); feat[3] += interval_feature<3>(c);
+            feat[4] += interval_feature<4>(c); feat[5] += interval_feature<5>(c);
+            feat[6] += interval_feature<6>(c); feat[7] += interval_feature<7>(c);
+            feat[8] += interval_feature<8>(c); feat[9] += interval_feature<9>(c);
         }
+        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int t = 0; t < 10; t++) {
-        // lanes 16..63 hold zeros; sum the 16 frames of this wave
+        // lanes 16..63 hold zeros; sum the 16 lanes (= 64 frames) of this tile
         double v = feat[t];
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-        if (lane == 0) part[wave][t] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 10) {
-        const int t = threadIdx.x;
-        chroma_part[(size_t)blockIdx.x * 10 + t] = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+        if (lane == 0) chroma_part[(size_t)(pfx_ct[s] + tile64) * 10 + t] = v;
     }
 }
 
 void launch_chroma(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
-    if (b.tiles_ct == 0) return;
-    hipLaunchKernelGGL(chroma_kernel, dim3(b.tiles_ct), dim3(256), 0, st, b.songs, b.n_songs, b.pfx_ct, w.spec,
+    if (b.tiles_cw == 0) return;
+    hipLaunchKernelGGL(chroma_kernel, dim3(b.tiles_cw), dim3(256), 0, st, b.songs, b.n_songs, b.pfx_cw, b.pfx_ct, w.spec,
                        t.chroma_bank, w.tuning, w.chroma_part);
 }
 

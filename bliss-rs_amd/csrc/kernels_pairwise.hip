@@ -15,6 +15,10 @@
 // HBM-write bound: 4 bytes per pair out, 4*d*(n+m) bytes in.  A workgroup owns a 128-row x 256-column
 // tile; each lane keeps 4 column vectors in registers, rows come from LDS as broadcasts, and every
 // wave-store is 64 lanes x 16 B = 1 KiB of one output row.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "device_utils.hpp"
 #include "internal.hpp"
 
@@ -23,7 +27,56 @@ namespace bg {
 constexpr int PW_ROWS = 128, PW_COLS = 256, PW_CPT = 4;  // tile rows, tile cols, cols per thread
 enum { METRIC_EUCLIDEAN = 0, METRIC_COSINE = 1, METRIC_MAHALANOBIS = 2 };
 
-// ndarray::numeric_util::unrolled_dot over compile-time length D; term(k) yields xs[k]*ys[k] operands
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F&&>(f));
+    }
+}
+__device__ __forceinline__ f2 splat(float x) { f2 r; r.x = x; r.y = x; return r; }
+
+// (a, a) - b and (a, a) * b where a is the LO (HI = false) or HI half of a register pair: the broadcast
+// is an op_sel modifier of the packed instruction instead of two v_mov per element
+template <bool HI>
+__device__ __forceinline__ f2 bsub(f2 apair, f2 b) {
+    f2 r;
+    if (HI) asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(apair), "v"(b));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(apair), "v"(b));
+    return r;
+}
+template <bool HI>
+__device__ __forceinline__ f2 bmul(f2 apair, f2 b) {
+    f2 r;
+    if (HI) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(apair), "v"(b));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(apair), "v"(b));
+    return r;
+}
+
+// ndarray::numeric_util::unrolled_dot over compile-time length D, evaluated for TWO pairs at once in packed
+// f32 (v_pk_mul_f32 / v_pk_add_f32: each half rounds exactly like the scalar op; this translation unit is
+// compiled with -ffp-contract=off so the multiply and the add stay separate, as in the reference).
+template <int D, typename FX, typename FY>
+__device__ __forceinline__ f2 unrolled_dot2(FX xs, FY ys) {
+    f2 p[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) p[u] = splat(0.0f);
+    constexpr int BODY = (D / 8) * 8;
+#pragma unroll
+    for (int k = 0; k < BODY; k++) p[k & 7] = p[k & 7] + xs(k) * ys(k);
+    f2 sum = splat(0.0f);
+    sum = sum + (p[0] + p[4]);
+    sum = sum + (p[1] + p[5]);
+    sum = sum + (p[2] + p[6]);
+    sum = sum + (p[3] + p[7]);
+#pragma unroll
+    for (int k = BODY; k < D; k++) sum = sum + xs(k) * ys(k);
+    return sum;
+}
+
 template <int D, typename FX, typename FY>
 __device__ __forceinline__ float unrolled_dot(FX xs, FY ys) {
     float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -40,21 +93,22 @@ __device__ __forceinline__ float unrolled_dot(FX xs, FY ys) {
     return sum;
 }
 
-template <int D, int METRIC, bool DIAG>
-__global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__ A, uint64_t n,
+template <int D, int METRIC, bool DIAG, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restrict__ A, uint64_t n,
                                                        const float* __restrict__ B, uint64_t m,
                                                        const float* __restrict__ M, float* __restrict__ out,
                                                        uint64_t ld_out) {
-    __shared__ float sa[PW_ROWS][D];
+    constexpr int DP = (D + 3) & ~3;  // LDS row pitch: 16-byte aligned rows -> ds_read_b128 broadcasts
+    __shared__ __attribute__((aligned(16))) float sa[PW_ROWS][DP];
     __shared__ float sna[PW_ROWS];
     __shared__ float sm[(METRIC == METRIC_MAHALANOBIS) ? D * D : 1];
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const uint64_t i0 = (uint64_t)blockIdx.y * PW_ROWS;
     const uint64_t j0 = (uint64_t)blockIdx.x * PW_COLS + (uint64_t)lane * PW_CPT;
 
-    // stage the row tile (contiguous PW_ROWS*D floats) and, for cosine, the row norms
+    // stage the row tile and, for cosine, the row norms
     const uint64_t rows_here = (n - i0 < (uint64_t)PW_ROWS) ? n - i0 : (uint64_t)PW_ROWS;
-    for (int e = tid; e < (int)rows_here * D; e += 256) (&sa[0][0])[e] = A[i0 * D + e];
+    for (int e = tid; e < (int)rows_here * D; e += 256) sa[e / D][e % D] = A[i0 * D + e];
     if (METRIC == METRIC_MAHALANOBIS)
         for (int e = tid; e < D * D; e += 256) sm[e] = M[e];
     __syncthreads();
@@ -66,60 +120,94 @@ __global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__
         __syncthreads();
     }
 
-    // the lane's 4 column vectors
-    float b[PW_CPT][D];
-    float nb[PW_CPT];
+    // the lane's 4 column vectors as two packed pairs: bp[h][k] = (B[j0+2h][k], B[j0+2h+1][k])
+    f2 bp[2][D];
+    f2 nb[2];
 #pragma unroll
-    for (int c = 0; c < PW_CPT; c++) {
-        const uint64_t j = j0 + c;
+    for (int h = 0; h < 2; h++) {
+        const uint64_t ja = j0 + 2 * h, jb = ja + 1;
 #pragma unroll
-        for (int k = 0; k < D; k++) b[c][k] = (j < m) ? B[j * D + k] : 0.0f;
-        if (METRIC == METRIC_COSINE)
-            nb[c] = sqrtf(unrolled_dot<D>([&](int k) { return b[c][k]; }, [&](int k) { return b[c][k]; }));
+        for (int k = 0; k < D; k++) {
+            bp[h][k].x = (ja < m) ? B[ja * D + k] : 0.0f;
+            bp[h][k].y = (jb < m) ? B[jb * D + k] : 0.0f;
+        }
+        if (METRIC == METRIC_COSINE) {
+            const f2 q = unrolled_dot2<D>([&](int k) { return bp[h][k]; }, [&](int k) { return bp[h][k]; });
+            nb[h].x = sqrtf(q.x);
+            nb[h].y = sqrtf(q.y);
+        }
     }
-    float wdiag[DIAG ? D : 1];
-    if (DIAG) {
+    float wdiag[D];
 #pragma unroll
-        for (int k = 0; k < D; k++) wdiag[k] = sm[k * D + k];
-    }
+    for (int k = 0; k < D; k++) wdiag[k] = DIAG ? sm[(k * D + k) % (METRIC == METRIC_MAHALANOBIS ? D * D : 1)] : 0.0f;
 
     const bool vec_ok = ((ld_out & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && (j0 + 3 < m);
     for (int r = wave; r < (int)rows_here; r += 4) {
-        float a[D];
+        f2 ap[DP / 2];  // the row, two features per register pair
 #pragma unroll
-        for (int k = 0; k < D; k++) a[k] = sa[r][k];  // same address in every lane: LDS broadcast
+        for (int k4 = 0; k4 < DP / 4; k4++) {  // same address in every lane: LDS broadcast
+            const float4 q = *reinterpret_cast<const float4*>(&sa[r][4 * k4]);
+            ap[2 * k4].x = q.x; ap[2 * k4].y = q.y; ap[2 * k4 + 1].x = q.z; ap[2 * k4 + 1].y = q.w;
+        }
         float res[PW_CPT];
 #pragma unroll
-        for (int c = 0; c < PW_CPT; c++) {
-            if (METRIC == METRIC_COSINE) {
-                const float ab = unrolled_dot<D>([&](int k) { return a[k]; }, [&](int k) { return b[c][k]; });
-                res[c] = 1.0f - ab / (sna[r] * nb[c]);
-            } else {
-                float v[D];
-#pragma unroll
-                for (int k = 0; k < D; k++) v[k] = a[k] - b[c][k];
-                float q;
-                if (METRIC == METRIC_EUCLIDEAN) {
-                    q = unrolled_dot<D>([&](int k) { return v[k]; }, [&](int k) { return v[k]; });
-                } else if (DIAG) {
-                    q = unrolled_dot<D>([&](int k) { return v[k] * wdiag[k]; }, [&](int k) { return v[k]; });
-                } else {
-                    float t[D];
+        for (int h = 0; h < 2; h++) {
+            // term k of the unrolled_dot for the two columns of pair h
+            auto term = [&](auto kc) -> f2 {
+                constexpr int k = decltype(kc)::value;
+                constexpr bool HI = (k & 1) != 0;
+                if (METRIC == METRIC_COSINE) return bmul<HI>(ap[k / 2], bp[h][k]);
+                const f2 v = bsub<HI>(ap[k / 2], bp[h][k]);
+                if (METRIC == METRIC_EUCLIDEAN) return v * v;
+                if (DIAG) return (v * splat(wdiag[k])) * v;
+                return v;  // unused (general M handled below)
+            };
+            f2 q;
+            if (METRIC == METRIC_MAHALANOBIS && !DIAG) {
+                f2 v[D], t[D];
+                static_for<D>([&](auto kc) { v[decltype(kc)::value] = term(kc); });
 #pragma unroll 1
-                    for (int jj = 0; jj < D; jj++) {
-                        float s = 0.0f;
+                for (int jj = 0; jj < D; jj++) {
+                    f2 acc = splat(0.0f);
 #pragma unroll
-                        for (int ii = 0; ii < D; ii++) s = s + v[ii] * sm[ii * D + jj];
-                        t[jj] = s;
-                    }
-                    q = unrolled_dot<D>([&](int k) { return t[k]; }, [&](int k) { return v[k]; });
+                    for (int ii = 0; ii < D; ii++) acc = acc + v[ii] * splat(sm[ii * D + jj]);
+                    t[jj] = acc;
                 }
-                res[c] = sqrtf(q);
+                const f2 sq = unrolled_dot2<D>([&](int k) { return t[k]; }, [&](int k) { return v[k]; });
+                q.x = sqrtf(sq.x);
+                q.y = sqrtf(sq.y);
+            } else {
+                f2 p[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) p[u] = splat(0.0f);
+                constexpr int BODY = (D / 8) * 8;
+                static_for<BODY>([&](auto kc) { constexpr int k = decltype(kc)::value; p[k & 7] = p[k & 7] + term(kc); });
+                f2 sum = splat(0.0f);
+                sum = sum + (p[0] + p[4]);
+                sum = sum + (p[1] + p[5]);
+                sum = sum + (p[2] + p[6]);
+                sum = sum + (p[3] + p[7]);
+                static_for<D - BODY>([&](auto kc) { sum = sum + term(std::integral_constant<int, BODY + decltype(kc)::value>{}); });
+                if (METRIC == METRIC_COSINE) {
+                    q = splat(1.0f) - sum / (splat(sna[r]) * nb[h]);
+                } else if (ABL == 1) {
+                    q = sum;
+                } else {
+                    q.x = sqrtf(sum.x);
+                    q.y = sqrtf(sum.y);
+                }
             }
+            res[2 * h] = q.x;
+            res[2 * h + 1] = q.y;
         }
         float* orow = out + (i0 + r) * ld_out + j0;
-        if (vec_ok) {
-            *reinterpret_cast<float4*>(orow) = make_float4(res[0], res[1], res[2], res[3]);
+        if (ABL == 2) {
+            if (res[0] == 123.456f || res[1] == 0.777f || res[2] == 3.25f || res[3] == 9.5f) orow[0] = 1.0f;
+        } else if (vec_ok) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 q4;
+            q4.x = res[0]; q4.y = res[1]; q4.z = res[2]; q4.w = res[3];
+            __builtin_nontemporal_store(q4, reinterpret_cast<f4*>(__builtin_assume_aligned(orow, 16)));  // written once, never re-read here
         } else {
 #pragma unroll
             for (int c = 0; c < PW_CPT; c++)
@@ -175,7 +263,12 @@ template <int D>
 static void launch_d(const float* A, uint64_t n, const float* B, uint64_t m, int metric, const float* M, int diag,
                      float* out, uint64_t ld, hipStream_t st) {
     const dim3 grid((uint32_t)((m + PW_COLS - 1) / PW_COLS), (uint32_t)((n + PW_ROWS - 1) / PW_ROWS));
-    if (metric == METRIC_EUCLIDEAN)
+    static const int abl = getenv("BLISSGPU_ABLPW") ? atoi(getenv("BLISSGPU_ABLPW")) : 0;
+    if (metric == METRIC_EUCLIDEAN && abl == 1)
+        hipLaunchKernelGGL((pairwise_kernel<D, METRIC_EUCLIDEAN, false, 1>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
+    else if (metric == METRIC_EUCLIDEAN && abl == 2)
+        hipLaunchKernelGGL((pairwise_kernel<D, METRIC_EUCLIDEAN, false, 2>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
+    else if (metric == METRIC_EUCLIDEAN)
         hipLaunchKernelGGL((pairwise_kernel<D, METRIC_EUCLIDEAN, false>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
     else if (metric == METRIC_COSINE)
         hipLaunchKernelGGL((pairwise_kernel<D, METRIC_COSINE, false>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
