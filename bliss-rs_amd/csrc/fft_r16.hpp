@@ -49,10 +49,20 @@ __device__ __forceinline__ f2 cmul_pk(f2 a, f2 w) {
     return r;
 }
 
+// a * w with a wave-uniform w held in an SGPR pair (compile-time twiddles: no v_mov per use)
+__device__ __forceinline__ f2 cmul_pk_s(f2 a, f2 w) {
+    f2 t, r;
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+        : "=v"(r), "=&v"(t)
+        : "v"(a), "s"(w));
+    return r;
+}
+
 // (-i) * a = (a.y, -a.x), 1 instruction (ones = (1, 1))
 __device__ __forceinline__ f2 mul_mi_pk(f2 a, f2 ones) {
     f2 r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(ones));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "s"(ones));
     return r;
 }
 
@@ -67,15 +77,15 @@ __device__ __forceinline__ void radix16(f2 (&v)[16]) {
 #pragma unroll
     for (int b = 0; b < 4; b++) radix4_pk(v[b], v[4 + b], v[8 + b], v[12 + b]);
     // twiddle u[b][c] *= W16^(b*c)   (element index 4c + b)
-    v[5] = cmul_pk(v[5], mk(C1, -S1));     // W^1
-    v[6] = cmul_pk(v[6], mk(R2, -R2));     // W^2
-    v[7] = cmul_pk(v[7], mk(S1, -C1));     // W^3
-    v[9] = cmul_pk(v[9], mk(R2, -R2));     // W^2
+    v[5] = cmul_pk_s(v[5], mk(C1, -S1));     // W^1
+    v[6] = cmul_pk_s(v[6], mk(R2, -R2));     // W^2
+    v[7] = cmul_pk_s(v[7], mk(S1, -C1));     // W^3
+    v[9] = cmul_pk_s(v[9], mk(R2, -R2));     // W^2
     v[10] = mul_mi_pk(v[10], mk(1.0f, 1.0f));  // W^4 = -i
-    v[11] = cmul_pk(v[11], mk(-R2, -R2));  // W^6
-    v[13] = cmul_pk(v[13], mk(S1, -C1));   // W^3
-    v[14] = cmul_pk(v[14], mk(-R2, -R2));  // W^6
-    v[15] = cmul_pk(v[15], mk(-C1, S1));   // W^9
+    v[11] = cmul_pk_s(v[11], mk(-R2, -R2));  // W^6
+    v[13] = cmul_pk_s(v[13], mk(S1, -C1));   // W^3
+    v[14] = cmul_pk_s(v[14], mk(-R2, -R2));  // W^6
+    v[15] = cmul_pk_s(v[15], mk(-C1, S1));   // W^9
     // layer 2: for each c, radix-4 over b on v[4c + b] -> X[c + 4d] at v[4c + d]
 #pragma unroll
     for (int c = 0; c < 4; c++) radix4_pk(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);

@@ -138,6 +138,52 @@ __device__ __forceinline__ uint32_t coarse_bin(double mag) {
     return b < (uint32_t)H1_BINS ? b : (uint32_t)H1_BINS - 1;
 }
 
+// `(double)se > ref` as an f32 comparison: thr = the largest float <= ref (then se > thr <=> (double)se > ref)
+__device__ __forceinline__ float ref_floor_f32(double ref) {
+    float f = (float)ref;
+    if ((double)f > ref) f = __uint_as_float(__float_as_uint(f) - 1u);  // ref >= 0, so f > 0 here
+    return f;
+}
+
+// The f64 interpolation above is only needed bit-exactly near a decision boundary.  For an established peak
+// (sa <= se, sb < se) the f32 evaluation below is within 2 ulp(se) of the f64 magnitude: |avg| <= den / 2
+// bounds the interpolation term by se / 8 and its error by ~0.5 ulp(se), den > 0 is never rounded to zero
+// (2 se - sa >= se > sb), plus two final roundings.  A 16-ulp guard band around the coarse-bin edges
+// (2^18 ulp apart) therefore makes the f32 bin provably equal to coarse_bin() of the f64 magnitude;
+// the ~1e-4 of peaks inside the band take the f64 path.
+__device__ __forceinline__ uint32_t peak_coarse_bin(float sb, float se, float sa, double ref, int c) {
+    const float avg = 0.5f * (sa - sb);
+    const float den = (2.0f * se - sa) - sb;
+    const float shift = avg * __builtin_amdgcn_rcpf(den);
+    const uint32_t bits = __float_as_uint(se + (0.5f * avg) * shift), low = bits & 0x3FFFFu;
+    if (se >= 1e-30f && low >= 16u && low <= 0x3FFFFu - 16u) {
+        const uint32_t b = bits >> 18;
+        return b < (uint32_t)H1_BINS ? b : (uint32_t)H1_BINS - 1;
+    }
+    double mag;
+    pip_peak_mag(sb, se, sa, ref, c, &mag);  // always true for c >= PIP_LO (pitch > 0)
+    return coarse_bin(mag);
+}
+
+// pitch-residue bin in f32, or -1 when it is not provably the f64 pitch_bin(): the peak must not be flat
+// (den >= 2^-10 se bounds the shift error by 1e-4, i.e. 3e-3 bins at c >= 57) and the bin coordinate must
+// be at least 0.02 away from an integer (v_log_f32 + f32 rounding stay below 3e-3 bins).
+__device__ __forceinline__ int peak_pitch_bin_f32(float sb, float se, float sa, int c) {
+    const float avg = 0.5f * (sa - sb);
+    const float den = (2.0f * se - sa) - sb;
+    if (!(se >= 1e-30f) || den < se * 0.0009765625f) return -1;
+    const float shift = avg * __builtin_amdgcn_rcpf(den);
+    // 12 log2(pitch / 27.5) with pitch = (c + shift) * 22050 / 8192
+    float x = 12.0f * (__builtin_amdgcn_logf((float)c + shift) + -3.3528687f);  // log2(22050 / 8192 / 27.5)
+    x = x - truncf(x);
+    if (x >= 0.5f) x -= 1.0f;
+    const float q = (x + 0.5f) * 100.0f;
+    const float fl = floorf(q), fr = q - fl;
+    if (fr < 0.02f || fr > 0.98f) return -1;
+    const int idx = (int)fl;
+    return idx < 0 ? 0 : (idx > N_TUNING - 1 ? N_TUNING - 1 : idx);
+}
+
 // ------------------------------------------------------------------------------------------------
 // STFT 8192 / hop 2205
 //
@@ -153,6 +199,12 @@ constexpr int EX1_PITCH = 257;   // k1-major rows of 256 (+1): the 16 lanes of a
 constexpr int EX2_PITCH = 272;   // j1-major rows of 256 (+16): shifts odd rows by 32 banks
 constexpr int STFT_LDS = 16 * EX2_PITCH;  // float2 elements (34 816 B)
 
+// W_32^j = (cos, -sin)(2 pi j / 32), j < 8
+__device__ constexpr float CONST_COS32[8] = {1.0f, 0.98078528040323044f, 0.92387953251128674f, 0.83146961230254524f,
+                                             0.70710678118654752f, 0.55557023301960222f, 0.38268343236508977f, 0.19509032201612827f};
+__device__ constexpr float CONST_SIN32[8] = {0.0f, 0.19509032201612827f, 0.38268343236508977f, 0.55557023301960222f,
+                                             0.70710678118654752f, 0.83146961230254524f, 0.92387953251128674f, 0.98078528040323044f};
+
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 // 8-byte load through a buffer descriptor: 32-bit lane offset + scalar offset (no 64-bit address VGPRs)
 __device__ __forceinline__ f2 buf_load_f2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
@@ -167,8 +219,8 @@ __device__ __forceinline__ long reflect_index(long p, long n) {
     return p;
 }
 
-template <int ABL>  // ABL != 0: timing ablations (developer aid, BLISSGPU_ABL), results are wrong
-__global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restrict__ pcm,
+template <int ABL, int OCC>  // ABL != 0: timing ablations (developer aid, BLISSGPU_ABL), results are wrong
+__global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restrict__ pcm,
                                                        const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                        const uint32_t* __restrict__ pfx_c,
                                                        const float* __restrict__ hann,
@@ -182,8 +234,6 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
     // a song's few hot histogram lines would otherwise serialise at the L2
     __shared__ uint32_t lhist[LHIST_BINS];
     __shared__ uint32_t lhist_base;
-    __shared__ uint16_t peak_list[PIP_MAX_PER_FRAME + 2];
-    __shared__ uint32_t peak_count;
     __shared__ f2 tw256[256];  // W_256^(m2*j1) at [16 j1 + m2] (pass-2 twiddles, broadcast reads)
     {
         const float2 a = tw[32 * (((threadIdx.x >> 4) * (threadIdx.x & 15)) & 255)];
@@ -199,23 +249,27 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
 
     // descriptors: window table (8192 f32) and twiddle table (8192 float2); wave-uniform
     const __amdgpu_buffer_rsrc_t r_hann = __builtin_amdgcn_make_buffer_rsrc((void*)hann, 0, W8192 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_tw = __builtin_amdgcn_make_buffer_rsrc((void*)tw, 0, W8192 * 8, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_p1 = __builtin_amdgcn_make_buffer_rsrc((void*)tw_p1, 0, 16 * 256 * 8, 0x00020000);
+
+
     const uint32_t t8 = 8u * (uint32_t)t;  // byte offset of (x[2t], x[2t+1]) / (hann[2t], hann[2t+1])
     // the window values of this thread's 16 complex inputs stay in registers for all frames of the tile
     f2 win[16];
 #pragma unroll
     for (int n1 = 0; n1 < 16; n1++) win[n1] = buf_load_f2(r_hann, t8, 2048u * n1);
+    // Twiddles come from a 256-entry LDS table and two per-thread constants instead of per-frame loads of
+    // 4096- and 2048-entry tables (every vector-memory load in the frame loop costs an in-order vmcnt wait):
+    //   pass 1:  W_4096^((16 m1 + m2) k1) = W_256^(m1 k1) * W_4096^(m2 k1); the second factor does not depend
+    //            on m1, so it commutes with the pass-2 DFT over m1 and is applied as the thread constant c_p2
+    //   split:   W_8192^(t + 256 j) = W_8192^t * W_32^j
+    f2 c_p2, c_sp;
+    {
+        const float2 a = tw[2 * hi4 * lo4], b = tw[t];
+        c_p2 = mk(a.x, a.y);
+        c_sp = mk(b.x, b.y);
+    }
     uint32_t* hist = h1 + (size_t)s * H1_BINS;
     for (int i = t; i < LHIST_BINS; i += 256) lhist[i] = 0;
     bool have_base = false;
-    // The magnitudes of a frame are written to HBM one iteration late, AFTER the next frame's loads have
-    // been issued: vmcnt retires in order, so loads issued behind 17 stores would wait for the stores'
-    // HBM round trip at the top of every frame.
-    float pend_lo[8], pend_hi[8], pend_mid = 0.0f;
-    float* pend_row = nullptr;
-#pragma unroll
-    for (int j = 0; j < 8; j++) { pend_lo[j] = 0.0f; pend_hi[j] = 0.0f; }
 
     // raw samples of one frame: z[256*n1 + t] = (x[w0 + 2n], x[w0 + 2n + 1]), reflect only at the song edges
     auto load_frame = [&](uint32_t f, f2 (&xr)[16]) {
@@ -225,14 +279,22 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
             for (int n1 = 0; n1 < 16; n1++) xr[n1] = mk((float)(t + n1 + (int)f), 1.0f);
         } else if (w0 >= 0 && w0 + W8192 <= n) {
             const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(ABL == 4 ? pcm + 4096 : x + w0), 0, W8192 * 4, 0x00020000);
+                (void*)(ABL == 4 ? pcm + 4096 : (ABL == 9 ? x + (w0 & ~3L) : x + w0)), 0, W8192 * 4, 0x00020000);
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) xr[n1] = buf_load_f2(r_x, t8, 2048u * n1);
         } else {
+            // numpy mode="reflect" (src/utils.rs:11-24) in 32-bit offsets relative to x + w0: positions before
+            // the song mirror about sample 0, positions past the end about sample n - 1
+            const int before = w0 < 0 ? (int)(-w0) : 0;
+            const long rel_l = n - w0;
+            const int rel = rel_l > 0x3fffffffL ? 0x3fffffff : (int)rel_l;
+            const float* __restrict__ xw = x + w0;
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
-                const long p = w0 + 2 * (256 * n1 + t);
-                xr[n1] = mk(x[reflect_index(p, n)], x[reflect_index(p + 1, n)]);
+                int q0 = 2 * (256 * n1 + t), q1 = q0 + 1;
+                q0 = q0 < before ? 2 * before - q0 : (q0 >= rel ? 2 * rel - 2 - q0 : q0);
+                q1 = q1 < before ? 2 * before - q1 : (q1 >= rel ? 2 * rel - 2 - q1 : q1);
+                xr[n1] = mk(xw[q0], xw[q1]);
             }
         }
     };
@@ -247,34 +309,21 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
         if (f >= sd.n_c) break;  // uniform
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window (src/utils.rs:37-39, :49)
-        // pass-1 twiddles W_4096^(t*k1) (lane-contiguous table), issued before the deferred stores
-        f2 twp[16];
-#pragma unroll
-        for (int k1 = 1; k1 < 16; k1++) twp[k1] = ABL == 5 ? mk(0.6f, 0.8f) : buf_load_f2(r_p1, t8, 2048u * k1);
-        if (pend_row != nullptr) {  // uniform: previous frame's magnitudes
-            if (ABL != 7) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    pend_row[t + 256 * j] = pend_lo[j];
-                    pend_row[4096 - (t + 256 * j)] = pend_hi[j];
-                }
-            }
-            if (t == 0) pend_row[2048] = pend_mid;
-            if (t >= 1 && t < CBINS_PAD - 4096) pend_row[4096 + t] = 0.0f;  // zero padding after bin 4096
-        }
-        // ---- pass 1: DFT over n1 at n2 = t ----
+        // ---- pass 1: DFT over n1 at n2 = t = 16 m1 + m2; twiddle W_256^(m1 k1) ----
         radix16(v);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; k1++) v[R16(k1)] = cmul_pk(v[R16(k1)], twp[k1]);
+        for (int k1 = 1; k1 < 16; k1++)
+            v[R16(k1)] = cmul_pk(v[R16(k1)], ABL == 5 ? mk(0.6f, 0.8f) : tw256[16 * k1 + hi4]);
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) lds[k1 * EX1_PITCH + t] = v[R16(k1)];
         __syncthreads();
-        // ---- pass 2: thread (k1 = lo4, m2 = hi4): DFT over m1; twiddle W_256^(m2*j1) ----
+        // ---- pass 2: thread (k1 = lo4, m2 = hi4): DFT over m1; twiddle W_4096^(m2 k1) * W_256^(m2 j1) ----
 #pragma unroll
         for (int m1 = 0; m1 < 16; m1++) v[m1] = ABL == 8 ? lds[t + 256 * m1] : lds[lo4 * EX1_PITCH + 16 * m1 + hi4];
         radix16(v);
+        v[R16(0)] = cmul_pk(v[R16(0)], c_p2);
 #pragma unroll
-        for (int j1 = 1; j1 < 16; j1++) v[R16(j1)] = cmul_pk(v[R16(j1)], tw256[16 * j1 + hi4]);  // W_256^(m2*j1)
+        for (int j1 = 1; j1 < 16; j1++) v[R16(j1)] = cmul_pk(v[R16(j1)], cmul_pk(tw256[16 * j1 + hi4], c_p2));
         __syncthreads();
 #pragma unroll
         for (int j1 = 0; j1 < 16; j1++) lds[j1 * EX2_PITCH + t] = v[R16(j1)];  // = j1*272 + m2*16 + k1
@@ -294,10 +343,14 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
         float mx = 0.0f;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
+            const float CJ = CONST_COS32[j], SJ = CONST_SIN32[j];
             const int k = t + 256 * j;
             float sq_k, sq_m;
             if (ABL == 2) { sq_k = v[R16(j)].x; sq_m = v[R16(j)].y; }
-            else split_pair_sq(v[R16(j)], lds[(4096 - k) & 4095], ABL == 6 ? mk(0.6f, 0.8f) : buf_load_f2(r_tw, t8, 2048u * j), sq_k, sq_m);
+            else {
+                const f2 w = ABL == 6 ? mk(0.6f, 0.8f) : (j == 0 ? c_sp : cmul_pk_s(c_sp, mk(CJ, -SJ)));
+                split_pair_sq(v[R16(j)], lds[(4096 - k) & 4095], w, sq_k, sq_m);
+            }
             m_lo[j] = mag_from_sq4(sq_k);
             m_hi[j] = mag_from_sq4(sq_m);
             mx = fmaxf(mx, fmaxf(m_lo[j], m_hi[j]));
@@ -306,10 +359,21 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
             m_mid = mag_from_sq4(split_one_sq(v[R16(8)], v[R16(8)], mk(0.0f, -1.0f)));  // k = 2048: W_8192^2048 = -i
             mx = fmaxf(mx, m_mid);
         }
-        pend_row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
+        // The magnitudes go to HBM BEFORE the next frame's loads are issued: vmcnt retires in order, so the
+        // only vector-memory wait of the loop (for those loads, at the top of the next iteration) also covers
+        // these stores, which by then have had the whole peak-picking phase to drain.
+        {
+            float* __restrict__ row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
+            if (ABL != 7) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) { pend_lo[j] = m_lo[j]; pend_hi[j] = m_hi[j]; }
-        pend_mid = m_mid;
+                for (int j = 0; j < 8; j++) {
+                    row[t + 256 * j] = m_lo[j];
+                    row[4096 - (t + 256 * j)] = m_hi[j];
+                }
+            }
+            if (t == 0) row[2048] = m_mid;
+            if (t >= 1 && t < CBINS_PAD - 4096) row[4096 + t] = 0.0f;  // zero padding after bin 4096
+        }
         if (fi + 1 < STFT_FRAMES_PER_WG && f + 1 < sd.n_c) load_frame(f + 1, v);  // uniform
         mx = wave_max(mx);
         __syncthreads();  // all split reads of lds are done
@@ -336,36 +400,21 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
         // ---- pip_track pass 1: count peaks by coarse magnitude bin.  Cheap test by every lane, the
         // peaks (about a third of the bins) are compacted so the f64 part runs on full wavefronts ----
         const double ref = 0.1 * (double)mx;
-        if (t == 0) peak_count = 0;
-        __syncthreads();
-        if (ABL != 1)
-        for (int c = PIP_LO + t; c < PIP_LO + 6 * 256; c += 256) {  // uniform trip count (ballots inside)
-            const bool pk = (c <= PIP_HI) && pip_is_peak(mags[c - 1], mags[c], mags[c + 1], ref);
-            wave_append(pk, c, peak_list, &peak_count);
-        }
-        __syncthreads();
-        const int n_peaks = (int)peak_count;
-        for (int i = t; i < n_peaks; i += 256) {
-            const int c = peak_list[i];
-            double mag;
-            if (pip_peak_mag(mags[c - 1], mags[c], mags[c + 1], ref, c, &mag)) {
-                const uint32_t b = coarse_bin(mag), rel = b - lbase;
-                if (rel < (uint32_t)LHIST_BINS) atomicAdd(&lhist[rel], 1u);
-                else atomicAdd(&hist[b], 1u);
+        const float thr = ref_floor_f32(ref);
+        if (ABL != 1) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const int c = t + 256 * j;
+                if (c < PIP_LO || c > PIP_HI) continue;
+                const float sb = mags[c - 1], se = mags[c], sa = mags[c + 1];
+                if (sa <= se && sb < se && se > thr) {
+                    const uint32_t b = peak_coarse_bin(sb, se, sa, ref, c), rel = b - lbase;
+                    if (rel < (uint32_t)LHIST_BINS) atomicAdd(&lhist[rel], 1u);
+                    else atomicAdd(&hist[b], 1u);
+                }
             }
         }
         __syncthreads();  // mags (lds) is reused by the next frame
-    }
-    if (pend_row != nullptr) {
-        if (ABL != 7) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                pend_row[t + 256 * j] = pend_lo[j];
-                pend_row[4096 - (t + 256 * j)] = pend_hi[j];
-            }
-        }
-        if (t == 0) pend_row[2048] = pend_mid;
-        if (t >= 1 && t < CBINS_PAD - 4096) pend_row[4096 + t] = 0.0f;
     }
     if (have_base) {
         const uint32_t lbase = lhist_base;
@@ -379,7 +428,8 @@ __global__ __launch_bounds__(256, 3) void stft8192_kernel(const float* __restric
 void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.tiles_c == 0) return;
     static const int abl = getenv("BLISSGPU_ABL") ? atoi(getenv("BLISSGPU_ABL")) : 0;
-#define LAUNCH_STFT(A) hipLaunchKernelGGL(stft8192_kernel<A>, dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, \
+    static const int occ = getenv("BLISSGPU_STFT_OCC") ? atoi(getenv("BLISSGPU_STFT_OCC")) : 3;
+#define LAUNCH_STFT(A) hipLaunchKernelGGL((stft8192_kernel<A, 3>), dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, \
                                           b.pfx_c, t.hann8192, t.tw8192, t.tw_p1, w.spec, w.frame_max, w.h1)
     if (abl == 1) LAUNCH_STFT(1);
     else if (abl == 2) LAUNCH_STFT(2);
@@ -389,6 +439,10 @@ void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, 
     else if (abl == 6) LAUNCH_STFT(6);
     else if (abl == 7) LAUNCH_STFT(7);
     else if (abl == 8) LAUNCH_STFT(8);
+    else if (abl == 9) LAUNCH_STFT(9);
+    else if (occ == 4)
+        hipLaunchKernelGGL((stft8192_kernel<0, 4>), dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs,
+                           b.pfx_c, t.hann8192, t.tw8192, t.tw_p1, w.spec, w.frame_max, w.h1);
     else LAUNCH_STFT(0);
 #undef LAUNCH_STFT
 }
@@ -449,6 +503,9 @@ void launch_tune_select(const Batch& b, const Workspace& w, hipStream_t st) {
 // tuning pass 2: re-run the peak test on the stored magnitudes; peaks above the median's coarse bin
 // go straight into the pitch histogram, peaks inside it are kept as candidates for the exact select
 // ------------------------------------------------------------------------------------------------
+constexpr int P2_SLOW_CAP = 1024;  // per-wave list of peaks that need the f64 path
+constexpr int P2_FRAMES_PER_WAVE = CH_TILE / 4;
+
 __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                          const uint32_t* __restrict__ pfx_ct,
                                                          const float* __restrict__ spec,
@@ -458,8 +515,8 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
                                                          double* __restrict__ cand_mag,
                                                          uint8_t* __restrict__ cand_pb) {
     __shared__ uint32_t hist[N_TUNING];
-    __shared__ uint16_t peak_list[4][PIP_MAX_PER_FRAME + 2];
-    __shared__ uint32_t peak_count[4];
+    __shared__ uint32_t slow_list[4][P2_SLOW_CAP];  // (frame slot << 16) | centre bin
+    __shared__ uint32_t slow_count[4];
     const uint32_t s = find_segment(pfx_ct, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
     const uint32_t tile = blockIdx.x - pfx_ct[s];
@@ -468,23 +525,19 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
     const uint32_t b_lo = ts->b_lo, b_hi = ts->b_hi;
     if (ts->n_peaks == 0) return;
     if (tid < N_TUNING) hist[tid] = 0;
+    if (lane == 0) slow_count[wave] = 0;
     __syncthreads();
-    for (int i = 0; i < CH_TILE / 4; i++) {
-        const uint32_t f = tile * CH_TILE + wave + 4 * i;
-        if (f >= sd.n_c) break;
-        const float* row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
-        const double ref = 0.1 * (double)frame_max[sd.c_off + f];
-        // cheap test by every lane, then the peaks are processed densely (one per lane)
-        if (lane == 0) peak_count[wave] = 0;
-        __builtin_amdgcn_wave_barrier();
-        for (int c = PIP_LO + lane; c < PIP_LO + 23 * WAVE; c += WAVE) {
-            const bool pk = (c <= PIP_HI) && pip_is_peak(row[c - 1], row[c], row[c + 1], ref);
-            wave_append(pk, c, peak_list[wave], &peak_count[wave]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int n_peaks = (int)peak_count[wave];
-        for (int i = lane; i < n_peaks; i += WAVE) {
-            const int c = peak_list[wave][i];
+    // wave w owns frames tile*CH_TILE + w + 4 i.  Most peaks are classified in f32 (see peak_coarse_bin /
+    // peak_pitch_bin_f32); the rest -- candidates inside the median's coarse bins and peaks whose f32 pitch
+    // bin is not provable -- are queued and run through the f64 path on densely packed wavefronts.
+    auto flush = [&]() {
+        const uint32_t n_slow = slow_count[wave];
+        for (uint32_t i = lane; i < n_slow; i += WAVE) {
+            const uint32_t e = slow_list[wave][i];
+            const int c = (int)(e & 0xFFFFu);
+            const uint32_t f = tile * CH_TILE + wave + 4 * (e >> 16);
+            const float* row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
+            const double ref = 0.1 * (double)frame_max[sd.c_off + f];
             double mag, pitch;
             if (pip_peak_core(row[c - 1], row[c], row[c + 1], ref, c, &mag, &pitch)) {
                 const uint32_t b = coarse_bin(mag);
@@ -497,7 +550,45 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) slow_count[wave] = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int i = 0; i < P2_FRAMES_PER_WAVE; i++) {
+        const uint32_t f = tile * CH_TILE + wave + 4 * i;
+        if (f >= sd.n_c) break;
+        const float* row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
+        const double ref = 0.1 * (double)frame_max[sd.c_off + f];
+        const float thr = ref_floor_f32(ref);
+        if (slow_count[wave] + PIP_MAX_PER_FRAME > P2_SLOW_CAP) flush();  // wave-uniform
+        float sb = row[PIP_LO - 1 + lane], se = row[PIP_LO + lane];
+        for (int c = PIP_LO + lane; c < PIP_LO + 23 * WAVE; c += WAVE) {  // uniform trip count (ballots inside)
+            const bool in = c <= PIP_HI;
+            const float sa = in ? row[c + 1] : 0.0f;
+            bool slow = false;
+            if (in && sa <= se && sb < se && se > thr) {
+                const uint32_t b = peak_coarse_bin(sb, se, sa, ref, c);
+                if (b > b_hi) {
+                    const int pb = peak_pitch_bin_f32(sb, se, sa, c);
+                    if (pb >= 0) atomicAdd(&hist[pb], 1u);
+                    else slow = true;
+                } else if (b >= b_lo) {
+                    slow = true;
+                }
+            }
+            const uint64_t mask = __ballot(slow);
+            if (mask) {
+                uint32_t base = 0;
+                if (lane == 0) { base = slow_count[wave]; slow_count[wave] = base + (uint32_t)__popcll(mask); }
+                base = __shfl(base, 0, WAVE);
+                if (slow) slow_list[wave][base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = ((uint32_t)i << 16) | (uint32_t)c;
+            }
+            // next stride: the three magnitudes are re-read (they are 63 bins further on)
+            sb = row[c + WAVE - 1];
+            se = row[c + WAVE];
+        }
     }
+    flush();
     __syncthreads();
     if (tid < N_TUNING && hist[tid]) atomicAdd(&hist100[(size_t)s * N_TUNING + tid], hist[tid]);
 }

@@ -1,0 +1,14 @@
+#!/bin/bash
+# HBM traffic of every analysis kernel: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit
+# one pass on gfx950), kernel-trace only.  usage (GPU box): SONGS=256 bash tests/tools/hbm_traffic.sh
+R=$PWD; cd /tmp; export TMPDIR=/tmp; export BLISSGPU_SERIAL=1
+S=${SONGS:-256}
+B="python $R/bench.py --songs $S --steps 1 --warmup 1 --no-cpu-baseline --no-pairwise"
+rm -rf $R/gpurun_out/hbm
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout ${PMC_TIMEOUT:-200} rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "bg::" --output-format csv -d $R/gpurun_out/hbm/$i -o p -- $B > $R/gpurun_out/hbm_$i.log 2>&1
+  echo "pass $i ($set) rc=$?"
+done
+cd $R; python tests/tools/hbm_traffic.py gpurun_out/hbm $S
