@@ -62,7 +62,7 @@ struct blissgpu_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // chroma chain + assembly (the caller-visible stream)
     hipStream_t aux_stream = nullptr;  // tempo / timbral / loudness chain, joined before the assembly
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_join = nullptr;
     bool serial = false;               // BLISSGPU_SERIAL=1: single stream (clean per-kernel timings)
     bool full_overlap = false;         // BLISSGPU_OVERLAP=2: the two FFT kernels also run concurrently
     uint64_t ws_limit = 96ull << 30;
@@ -314,7 +314,12 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
         { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
         HIP_TRY(hipEventRecord(c->ev_join, sb));
     } else {
-        { Prof p(c, K_PCM_STATS); launch_pcm_stats(b, w, st); }
+        // the HBM-bound PCM statistics pass (only the aux chain consumes it) runs beside the VALU-bound FFT-512
+        if (!c->serial) {
+            HIP_TRY(hipEventRecord(c->ev_start, st));
+            HIP_TRY(hipStreamWaitEvent(sb, c->ev_start, 0));
+        }
+        { Prof p(c, K_PCM_STATS, sb); launch_pcm_stats(b, w, sb); }
         { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st); }
         { Prof p(c, K_ONSET); launch_onset(b, w, st); }
         if (!c->serial) {
@@ -392,6 +397,7 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
     if (se != hipSuccess) { delete c; return fail(BLISSGPU_ERR_HIP, "hipStreamCreate", hipGetErrorString(se)); }
     c->stream = c->own_stream;
     se = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (se != hipSuccess) { blissgpu_ctx_destroy(c); return fail(BLISSGPU_ERR_HIP, "aux stream/events", hipGetErrorString(se)); }
@@ -414,6 +420,7 @@ int blissgpu_ctx_destroy(blissgpu_ctx* c) {
     c->slab.release(); c->desc.release(); c->dbg_tuning.release(); c->dbg_nbpms.release();
     if (c->h_desc) (void)hipHostFree(c->h_desc);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

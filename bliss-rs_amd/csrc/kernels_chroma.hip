@@ -206,6 +206,7 @@ __device__ constexpr float CONST_SIN32[8] = {0.0f, 0.19509032201612827f, 0.38268
                                              0.70710678118654752f, 0.83146961230254524f, 0.92387953251128674f, 0.98078528040323044f};
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 // 8-byte load through a buffer descriptor: 32-bit lane offset + scalar offset (no 64-bit address VGPRs)
 __device__ __forceinline__ f2 buf_load_f2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
         const float2 a = tw[2 * hi4 * lo4], b = tw[t];
         c_p2 = mk(a.x, a.y);
         c_sp = mk(b.x, b.y);
+        asm volatile("" : "+v"(c_p2), "+v"(c_sp));  // consume here: no vmcnt wait on them inside the frame loop
     }
     uint32_t* hist = h1 + (size_t)s * H1_BINS;
     for (int i = t; i < LHIST_BINS; i += 256) lhist[i] = 0;
@@ -302,13 +304,18 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
     // The next frame's samples are requested as soon as the current frame's registers are free (after the
     // split), so their HBM/L2 latency overlaps the peak-picking phase instead of stalling the next frame.
     f2 v[16];
-    if (tile * STFT_FRAMES_PER_WG < sd.n_c) load_frame(tile * STFT_FRAMES_PER_WG, v);
+    // The window multiply (the first use of the prefetched samples, i.e. the vmcnt wait) sits at the END of the
+    // loop body: there every path has issued the loads followed by the stores, so the wait is "all but the
+    // stores"; at the loop head the prologue path (no stores) would force a full vmcnt(0) drain per frame.
+    if (tile * STFT_FRAMES_PER_WG < sd.n_c) {
+        load_frame(tile * STFT_FRAMES_PER_WG, v);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window (src/utils.rs:37-39, :49)
+    }
 #pragma unroll 1
     for (int fi = 0; fi < STFT_FRAMES_PER_WG; fi++) {
         const uint32_t f = tile * STFT_FRAMES_PER_WG + fi;
         if (f >= sd.n_c) break;  // uniform
-#pragma unroll
-        for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window (src/utils.rs:37-39, :49)
         // ---- pass 1: DFT over n1 at n2 = t = 16 m1 + m2; twiddle W_256^(m1 k1) ----
         radix16(v);
 #pragma unroll
@@ -325,13 +332,15 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
 #pragma unroll
         for (int j1 = 1; j1 < 16; j1++) v[R16(j1)] = cmul_pk(v[R16(j1)], cmul_pk(tw256[16 * j1 + hi4], c_p2));
         __syncthreads();
+        if (ABL != 11 && ABL != 12) {
 #pragma unroll
-        for (int j1 = 0; j1 < 16; j1++) lds[j1 * EX2_PITCH + t] = v[R16(j1)];  // = j1*272 + m2*16 + k1
-        __syncthreads();
-        // ---- pass 3: thread (k1 = lo4, j1 = hi4): DFT over m2 -> Z[t + 256*j2] ----
+            for (int j1 = 0; j1 < 16; j1++) lds[j1 * EX2_PITCH + t] = v[R16(j1)];  // = j1*272 + m2*16 + k1
+            __syncthreads();
+            // ---- pass 3: thread (k1 = lo4, j1 = hi4): DFT over m2 -> Z[t + 256*j2] ----
 #pragma unroll
-        for (int m2 = 0; m2 < 16; m2++) v[m2] = lds[hi4 * EX2_PITCH + 16 * m2 + lo4];
-        radix16(v);
+            for (int m2 = 0; m2 < 16; m2++) v[m2] = lds[hi4 * EX2_PITCH + 16 * m2 + lo4];
+        }
+        if (ABL != 11) radix16(v);
         __syncthreads();
 #pragma unroll
         for (int j2 = 0; j2 < 16; j2++) lds[t + 256 * j2] = v[R16(j2)];
@@ -359,22 +368,8 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
             m_mid = mag_from_sq4(split_one_sq(v[R16(8)], v[R16(8)], mk(0.0f, -1.0f)));  // k = 2048: W_8192^2048 = -i
             mx = fmaxf(mx, m_mid);
         }
-        // The magnitudes go to HBM BEFORE the next frame's loads are issued: vmcnt retires in order, so the
-        // only vector-memory wait of the loop (for those loads, at the top of the next iteration) also covers
-        // these stores, which by then have had the whole peak-picking phase to drain.
-        {
-            float* __restrict__ row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
-            if (ABL != 7) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    row[t + 256 * j] = m_lo[j];
-                    row[4096 - (t + 256 * j)] = m_hi[j];
-                }
-            }
-            if (t == 0) row[2048] = m_mid;
-            if (t >= 1 && t < CBINS_PAD - 4096) row[4096 + t] = 0.0f;  // zero padding after bin 4096
-        }
-        if (fi + 1 < STFT_FRAMES_PER_WG && f + 1 < sd.n_c) load_frame(f + 1, v);  // uniform
+        const bool has_next = fi + 1 < STFT_FRAMES_PER_WG && f + 1 < sd.n_c;  // uniform
+        if (has_next) load_frame(f + 1, v);
         mx = wave_max(mx);
         __syncthreads();  // all split reads of lds are done
         float* mags = reinterpret_cast<float*>(lds);
@@ -384,8 +379,22 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
             mags[4096 - (t + 256 * j)] = m_hi[j];
         }
         if (t == 0) mags[2048] = m_mid;
+        if (t >= 1 && t < CBINS_PAD - 4096) mags[4096 + t] = 0.0f;  // zero padding after bin 4096
         if (lane_id() == 0) red[wave_id()] = mx;
         __syncthreads();
+        // The spectrogram row goes to HBM from the LDS copy as 16-byte stores (5 per thread instead of 18 scalar
+        // ones).  They are issued BEHIND the next frame's loads: vmcnt retires in order, so the wait for those
+        // loads at the end of the iteration is "all but the stores" and never waits for an HBM write acknowledge.
+        if (ABL != 7) {
+            const __amdgpu_buffer_rsrc_t r_row = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(spec + (sd.c_off + f) * (size_t)CBINS_PAD), 0, CBINS_PAD * 4, 0x00020000);
+            const u32x4_t* mags4 = reinterpret_cast<const u32x4_t*>(lds);
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int q = t + 256 * i;
+                if (i < 4 || q < CBINS_PAD / 4) __builtin_amdgcn_raw_buffer_store_b128(mags4[q], r_row, 16u * (uint32_t)q, 0, 0);
+            }
+        }
         mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         if (t == 0) frame_max[sd.c_off + f] = mx;
         if (!have_base) {  // uniform: anchor the LDS window LHIST_BINS/2 bins below the first frame's maximum
@@ -409,10 +418,15 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
                 const float sb = mags[c - 1], se = mags[c], sa = mags[c + 1];
                 if (sa <= se && sb < se && se > thr) {
                     const uint32_t b = peak_coarse_bin(sb, se, sa, ref, c), rel = b - lbase;
-                    if (rel < (uint32_t)LHIST_BINS) atomicAdd(&lhist[rel], 1u);
+                    if (ABL == 13) { if (rel == 0x7fffffffu) lhist[0] = 1; }
+                    else if (rel < (uint32_t)LHIST_BINS) atomicAdd(&lhist[rel], 1u);
                     else atomicAdd(&hist[b], 1u);
                 }
             }
+        }
+        if (has_next) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window of the next frame
         }
         __syncthreads();  // mags (lds) is reused by the next frame
     }
@@ -440,6 +454,9 @@ void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, 
     else if (abl == 7) LAUNCH_STFT(7);
     else if (abl == 8) LAUNCH_STFT(8);
     else if (abl == 9) LAUNCH_STFT(9);
+    else if (abl == 11) LAUNCH_STFT(11);
+    else if (abl == 12) LAUNCH_STFT(12);
+    else if (abl == 13) LAUNCH_STFT(13);
     else if (occ == 4)
         hipLaunchKernelGGL((stft8192_kernel<0, 4>), dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs,
                            b.pfx_c, t.hann8192, t.tw8192, t.tw_p1, w.spec, w.frame_max, w.h1);
