@@ -62,9 +62,9 @@ struct blissgpu_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // chroma chain + assembly (the caller-visible stream)
     hipStream_t aux_stream = nullptr;  // tempo / timbral / loudness chain, joined before the assembly
-    hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_stft = nullptr, ev_join = nullptr;
     bool serial = false;               // BLISSGPU_SERIAL=1: single stream (clean per-kernel timings)
-    bool full_overlap = false;         // BLISSGPU_OVERLAP=2: the two FFT kernels also run concurrently
+    int overlap_mode = 0;              // BLISSGPU_OVERLAP=1: start the per-song tails before the FFT-8192 kernel (experiment)
     uint64_t ws_limit = 96ull << 30;
     // tables
     float2 *tw8192 = nullptr, *tw512 = nullptr, *tw_p1 = nullptr;
@@ -303,42 +303,39 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
     // tempo / timbral chains (one workgroup per song: sequential beat tracker, sequential summaries)
     // run beside the chroma chain on the aux stream and are joined before the feature rows are written.
     hipStream_t st = c->stream, sb = c->serial ? c->stream : c->aux_stream;
-    if (c->full_overlap && !c->serial) {
-        // whole tempo/timbral chain beside the chroma chain
-        HIP_TRY(hipEventRecord(c->ev_fork, st));
-        HIP_TRY(hipStreamWaitEvent(sb, c->ev_fork, 0));
-        { Prof p(c, K_PCM_STATS, sb); launch_pcm_stats(b, w, sb); }
-        { Prof p(c, K_FFT512, sb); launch_fft512(b, w, c->tables, sb); }
-        { Prof p(c, K_ONSET, sb); launch_onset(b, w, sb); }
-        { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
-        { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
-        HIP_TRY(hipEventRecord(c->ev_join, sb));
-    } else {
-        // the HBM-bound PCM statistics pass (only the aux chain consumes it) runs beside the VALU-bound FFT-512
-        if (!c->serial) {
-            HIP_TRY(hipEventRecord(c->ev_start, st));
-            HIP_TRY(hipStreamWaitEvent(sb, c->ev_start, 0));
-        }
-        { Prof p(c, K_PCM_STATS, sb); launch_pcm_stats(b, w, sb); }
-        { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st); }
-        { Prof p(c, K_ONSET); launch_onset(b, w, st); }
-        if (!c->serial) {
-            HIP_TRY(hipEventRecord(c->ev_fork, st));
-            HIP_TRY(hipStreamWaitEvent(sb, c->ev_fork, 0));
-        }
-        { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
-        { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
-        if (!c->serial) HIP_TRY(hipEventRecord(c->ev_join, sb));
+    const bool two = !c->serial;
+    if (two) {
+        HIP_TRY(hipEventRecord(c->ev_start, st));
+        HIP_TRY(hipStreamWaitEvent(sb, c->ev_start, 0));
     }
-
+    // aux: the HBM-bound PCM statistics pass (only the aux chain consumes it) runs beside the VALU-bound FFT-512
+    { Prof p(c, K_PCM_STATS, sb); launch_pcm_stats(b, w, sb); }
+    { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st); }
+    { Prof p(c, K_ONSET); launch_onset(b, w, st); }
     HIP_TRY(hipMemsetAsync(w.h1, 0, (size_t)ns * H1_BINS * 4, st));
     HIP_TRY(hipMemsetAsync(w.hist100, 0, (size_t)ns * N_TUNING * 4, st));
+    // aux: the sequential summaries (one lane per song, a few hundred wavefronts in all, memory-latency bound)
+    // start as soon as the FFT-512 series exist and run beside the FFT-8192 kernel
+    if (two) {
+        HIP_TRY(hipEventRecord(c->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(sb, c->ev_fork, 0));
+    }
+    { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
     { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st); }
+    // The beat tracker (one 256-thread workgroup per song) would displace one of the three FFT-8192 workgroups
+    // per CU (168 VGPRs each), so it starts only after that kernel and runs beside the HBM-bound tuning / chroma
+    // kernels, which leave registers free.  BLISSGPU_OVERLAP=1 (experiment): start it beside the FFT-8192 kernel.
+    if (two && c->overlap_mode != 1) {
+        HIP_TRY(hipEventRecord(c->ev_stft, st));
+        HIP_TRY(hipStreamWaitEvent(sb, c->ev_stft, 0));
+    }
+    { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
+    if (two) HIP_TRY(hipEventRecord(c->ev_join, sb));
     { Prof p(c, K_TUNE_SELECT); launch_tune_select(b, w, st); }
     { Prof p(c, K_TUNE_PASS2); launch_tune_pass2(b, w, st); }
     { Prof p(c, K_TUNE_FINAL); launch_tune_final(b, w, st); }
     { Prof p(c, K_CHROMA); launch_chroma(b, w, c->tables, st); }
-    if (!c->serial) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
+    if (two) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
     { Prof p(c, K_FINALIZE); launch_finalize(b, w, features_version, d_out, c->dbg_tuning.p, c->dbg_nbpms.p, st); }
     HIP_TRY(hipGetLastError());
     return BLISSGPU_OK;
@@ -399,10 +396,11 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
     se = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_stft, hipEventDisableTiming);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (se != hipSuccess) { blissgpu_ctx_destroy(c); return fail(BLISSGPU_ERR_HIP, "aux stream/events", hipGetErrorString(se)); }
     if (const char* e = getenv("BLISSGPU_SERIAL")) c->serial = (e[0] == '1');
-    if (const char* e = getenv("BLISSGPU_OVERLAP")) c->full_overlap = (e[0] == '2');
+    if (const char* e = getenv("BLISSGPU_OVERLAP")) c->overlap_mode = atoi(e);
     int rc = build_tables(c);
     if (rc) { blissgpu_ctx_destroy(c); return rc; }
     *out = c;
@@ -422,6 +420,7 @@ int blissgpu_ctx_destroy(blissgpu_ctx* c) {
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_stft) (void)hipEventDestroy(c->ev_stft);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

@@ -16,21 +16,35 @@ namespace bg {
 
 __device__ __forceinline__ float normalize(float v, float mn, float mx) { return 2.0f * (v - mn) / (mx - mn) - 1.0f; }
 
-// The loops below are sequential by definition (they reproduce the reference's rounding order); the
-// loads are issued 16 at a time so the dependent arithmetic chain never waits on memory.
+// The loops below are sequential by definition (they reproduce the reference's rounding order).  A wavefront
+// executing ONE such chain still pays a full 4-cycle VALU issue per instruction, so the mapping is one LANE per
+// song: 64 songs advance their (independent) chains in lock step and a role costs 1/64 of the issue slots.
+// Loads are issued 16 elements at a time (16-byte loads once the lane's cursor is aligned) so the dependent
+// arithmetic chain never waits on memory.
 constexpr int SEQ_CHUNK = 16;
+
+template <typename Step>
+__device__ __forceinline__ void seq_for_each(const float* __restrict__ x, uint32_t n, Step&& step) {
+    uint32_t i = 0;
+    while (i < n && ((reinterpret_cast<uintptr_t>(x + i) & 15) != 0)) { step(x[i], i); i++; }
+    for (; i + SEQ_CHUNK <= n; i += SEQ_CHUNK) {
+        float4 v[SEQ_CHUNK / 4];
+#pragma unroll
+        for (int u = 0; u < SEQ_CHUNK / 4; u++) v[u] = *reinterpret_cast<const float4*>(x + i + 4 * u);
+#pragma unroll
+        for (int u = 0; u < SEQ_CHUNK / 4; u++) {
+            step(v[u].x, i + 4 * u);
+            step(v[u].y, i + 4 * u + 1);
+            step(v[u].z, i + 4 * u + 2);
+            step(v[u].w, i + 4 * u + 3);
+        }
+    }
+    for (; i < n; i++) step(x[i], i);
+}
 
 __device__ float seq_mean(const float* __restrict__ x, uint32_t n) {
     float s = 0.0f;
-    uint32_t i = 0;
-    for (; i + SEQ_CHUNK <= n; i += SEQ_CHUNK) {
-        float v[SEQ_CHUNK];
-#pragma unroll
-        for (int u = 0; u < SEQ_CHUNK; u++) v[u] = x[i + u];
-#pragma unroll
-        for (int u = 0; u < SEQ_CHUNK; u++) s += v[u];
-    }
-    for (; i < n; i++) s += x[i];
+    seq_for_each(x, n, [&](float v, uint32_t) { s += v; });
     return s / (float)n;
 }
 
@@ -43,37 +57,28 @@ __device__ __forceinline__ void welford_step(float v, uint32_t i, float& mean, f
 
 __device__ float seq_std(const float* __restrict__ x, uint32_t n) {
     float mean = 0.0f, sum_sq = 0.0f;
-    uint32_t i = 0;
-    for (; i + SEQ_CHUNK <= n; i += SEQ_CHUNK) {
-        float v[SEQ_CHUNK];
-#pragma unroll
-        for (int u = 0; u < SEQ_CHUNK; u++) v[u] = x[i + u];
-#pragma unroll
-        for (int u = 0; u < SEQ_CHUNK; u++) welford_step(v[u], i + u, mean, sum_sq);
-    }
-    for (; i < n; i++) welford_step(x[i], i, mean, sum_sq);
+    seq_for_each(x, n, [&](float v, uint32_t i) { welford_step(v, i, mean, sum_sq); });
     return sqrtf(sum_sq / ((float)n - 0.0f));
 }
 
-// roles: one wavefront each (lane 0 works) so the latency-bound sequential loops of one song overlap;
-// songs run in parallel across workgroups
 enum Role { R_CENT_MEAN = 0, R_CENT_STD, R_ROLL_MEAN, R_ROLL_STD, R_FLAT_MEAN, R_FLAT_STD, R_LOUD, R_ZCR, R_COUNT };
 
 // summary[s][0..15]: slots 1..9 = features 1..9 (zcr, centroid, rolloff, flatness, loudness)
-__global__ __launch_bounds__(64 * 8) void summary_kernel(const SongDesc* __restrict__ songs,
-                                                         const float* __restrict__ centroid,
-                                                         const float* __restrict__ rolloff,
-                                                         const float* __restrict__ flatness,
-                                                         const float* __restrict__ e256,
-                                                         const uint32_t* __restrict__ zc256,
-                                                         float* __restrict__ summary) {
-    const uint32_t s = blockIdx.x;
+// grid = (ceil(n_songs / 64), R_COUNT): one wavefront = one role of 64 songs (lane = song)
+__global__ __launch_bounds__(64) void summary_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs,
+                                                     const float* __restrict__ centroid,
+                                                     const float* __restrict__ rolloff,
+                                                     const float* __restrict__ flatness,
+                                                     const float* __restrict__ e256,
+                                                     const uint32_t* __restrict__ zc256,
+                                                     float* __restrict__ summary) {
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_songs) return;
     const SongDesc sd = songs[s];
     if (!sd.ok) return;
     float* feat = summary + (size_t)s * 16;
     const float half_sr = (float)SAMPLE_RATE / 2.0f;
-    const int role = (lane_id() == 0) ? wave_id() : -1;
-    switch (role) {
+    switch ((int)blockIdx.y) {  // wave-uniform
         case R_CENT_MEAN: feat[2] = normalize(seq_mean(centroid + sd.t_off, sd.n_t), 0.0f, half_sr); break;
         case R_CENT_STD: feat[3] = normalize(seq_std(centroid + sd.t_off, sd.n_t), 0.0f, half_sr); break;
         case R_ROLL_MEAN: feat[4] = normalize(seq_mean(rolloff + sd.t_off, sd.n_t), 0.0f, half_sr); break;
@@ -167,8 +172,8 @@ __global__ __launch_bounds__(64) void assemble_kernel(const SongDesc* __restrict
 
 void launch_summary(const Batch& b, const Workspace& w, hipStream_t st) {
     if (b.n_songs == 0) return;
-    hipLaunchKernelGGL(summary_kernel, dim3(b.n_songs), dim3(64 * R_COUNT), 0, st, b.songs, w.centroid, w.rolloff,
-                       w.flatness, w.e256, w.zc256, w.summary);
+    hipLaunchKernelGGL(summary_kernel, dim3((b.n_songs + 63) / 64, R_COUNT), dim3(64), 0, st, b.songs, b.n_songs, w.centroid,
+                       w.rolloff, w.flatness, w.e256, w.zc256, w.summary);
 }
 
 void launch_finalize(const Batch& b, const Workspace& w, uint32_t features_version, float* d_out, int32_t* dbg_tuning,
