@@ -17,6 +17,8 @@
 #include <float.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "device_utils.hpp"
 #include "fft_r16.hpp"
 #include "internal.hpp"
@@ -775,20 +777,38 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
     double4_t acc[4][2];
 #pragma unroll
     for (int q = 0; q < 4; q++) { acc[q][0] = double4_t{0.0, 0.0, 0.0, 0.0}; acc[q][1] = double4_t{0.0, 0.0, 0.0, 0.0}; }
-#pragma unroll 2
-    for (int st = 0; st < CBINS_PAD / 16; st++) {
-        const double4_t a = *reinterpret_cast<const double4_t*>(arow + 16 * st);
+    // K loop in groups of KU steps: all loads of a group are issued before its first MFMA, so the later steps'
+    // loads are in flight while the earlier steps' MFMAs run (a load -> drain -> MFMA loop per step cannot cover
+    // the HBM latency with two waves per SIMD).  No loaded value is carried across iterations: that form made
+    // the compiler shuttle the 64 accumulator registers between VGPRs and AGPRs every step.
+    constexpr int KSTEPS = CBINS_PAD / 16, KU = 4;
+    auto k_group = [&](int st0, auto nsteps) {
+        constexpr int NS = decltype(nsteps)::value;
+        double4_t a[NS];
+        float4 b[NS][4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 b = *reinterpret_cast<const float4*>(brow[q] + 16 * st);
-            const double b0 = (double)b.x * (double)b.x, b1 = (double)b.y * (double)b.y;
-            const double b2 = (double)b.z * (double)b.z, b3 = (double)b.w * (double)b.w;
-            acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0, acc[q][0], 0, 0, 0);
-            acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b1, acc[q][1], 0, 0, 0);
-            acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.z, b2, acc[q][0], 0, 0, 0);
-            acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.w, b3, acc[q][1], 0, 0, 0);
+        for (int u = 0; u < NS; u++) {
+            a[u] = *reinterpret_cast<const double4_t*>(arow + 16 * (st0 + u));
+#pragma unroll
+            for (int q = 0; q < 4; q++) b[u][q] = *reinterpret_cast<const float4*>(brow[q] + 16 * (st0 + u));
         }
-    }
+#pragma unroll
+        for (int u = 0; u < NS; u++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double b0 = (double)b[u][q].x * (double)b[u][q].x, b1 = (double)b[u][q].y * (double)b[u][q].y;
+                const double b2 = (double)b[u][q].z * (double)b[u][q].z, b3 = (double)b[u][q].w * (double)b[u][q].w;
+                acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b0, acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b1, acc[q][1], 0, 0, 0);
+                acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].z, b2, acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].w, b3, acc[q][1], 0, 0, 0);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int st = 0; st + KU <= KSTEPS; st += KU) k_group(st, std::integral_constant<int, KU>{});
+    static_assert(KSTEPS % KU == 1, "tail below handles exactly one step");
+    k_group(KSTEPS - 1, std::integral_constant<int, 1>{});
     double feat[10];
 #pragma unroll
     for (int t = 0; t < 10; t++) feat[t] = 0.0;
