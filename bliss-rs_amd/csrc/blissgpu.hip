@@ -309,11 +309,29 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
         HIP_TRY(hipStreamWaitEvent(sb, c->ev_start, 0));
     }
     // aux: the HBM-bound PCM statistics pass (only the aux chain consumes it) runs beside the VALU-bound FFT-512
+    HIP_TRY(hipMemsetAsync(w.h1, 0, (size_t)ns * H1_BINS * 4, st));
+    HIP_TRY(hipMemsetAsync(w.hist100, 0, (size_t)ns * N_TUNING * 4, st));
+    if (two && c->overlap_mode == 2) {
+        // experiment: the whole tempo / timbral chain on the aux stream, concurrent with the chroma chain
+        { Prof p(c, K_PCM_STATS, sb); launch_pcm_stats(b, w, sb); }
+        { Prof p(c, K_FFT512, sb); launch_fft512(b, w, c->tables, sb); }
+        { Prof p(c, K_ONSET, sb); launch_onset(b, w, sb); }
+        { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
+        { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
+        HIP_TRY(hipEventRecord(c->ev_join, sb));
+        { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st); }
+        { Prof p(c, K_TUNE_SELECT); launch_tune_select(b, w, st); }
+        { Prof p(c, K_TUNE_PASS2); launch_tune_pass2(b, w, st); }
+        { Prof p(c, K_TUNE_FINAL); launch_tune_final(b, w, st); }
+        { Prof p(c, K_CHROMA); launch_chroma(b, w, c->tables, st); }
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
+        { Prof p(c, K_FINALIZE); launch_finalize(b, w, features_version, d_out, c->dbg_tuning.p, c->dbg_nbpms.p, st); }
+        HIP_TRY(hipGetLastError());
+        return BLISSGPU_OK;
+    }
     { Prof p(c, K_PCM_STATS, sb); launch_pcm_stats(b, w, sb); }
     { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st); }
     { Prof p(c, K_ONSET); launch_onset(b, w, st); }
-    HIP_TRY(hipMemsetAsync(w.h1, 0, (size_t)ns * H1_BINS * 4, st));
-    HIP_TRY(hipMemsetAsync(w.hist100, 0, (size_t)ns * N_TUNING * 4, st));
     // aux: the sequential summaries (one lane per song, a few hundred wavefronts in all, memory-latency bound)
     // start as soon as the FFT-512 series exist and run beside the FFT-8192 kernel
     if (two) {

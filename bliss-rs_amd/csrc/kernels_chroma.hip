@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
         radix16(v);
 #pragma unroll
         for (int k1 = 1; k1 < 16; k1++)
-            v[R16(k1)] = cmul_pk(v[R16(k1)], ABL == 5 ? mk(0.6f, 0.8f) : tw256[16 * k1 + hi4]);
+            v[R16(k1)] = cmul_pk(v[R16(k1)], (ABL == 5 || ABL == 14) ? mk(0.6f, 0.8f) : tw256[16 * k1 + hi4]);
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) lds[k1 * EX1_PITCH + t] = v[R16(k1)];
         __syncthreads();
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
         radix16(v);
         v[R16(0)] = cmul_pk(v[R16(0)], c_p2);
 #pragma unroll
-        for (int j1 = 1; j1 < 16; j1++) v[R16(j1)] = cmul_pk(v[R16(j1)], cmul_pk(tw256[16 * j1 + hi4], c_p2));
+        for (int j1 = 1; j1 < 16; j1++) v[R16(j1)] = cmul_pk(v[R16(j1)], cmul_pk(ABL == 14 ? mk(0.6f, 0.8f + j1) : tw256[16 * j1 + hi4], c_p2));
         __syncthreads();
         if (ABL != 11 && ABL != 12) {
 #pragma unroll
@@ -344,8 +344,13 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
         }
         if (ABL != 11) radix16(v);
         __syncthreads();
+        // only the upper half (bins 2049..4095, the mirrors of this workgroup's bins 1..2047) is ever read back
 #pragma unroll
-        for (int j2 = 0; j2 < 16; j2++) lds[t + 256 * j2] = v[R16(j2)];
+        for (int j2 = 8; j2 < 16; j2++) lds[t + 256 * j2] = v[R16(j2)];
+        if (ABL == 15) {
+#pragma unroll
+            for (int j2 = 0; j2 < 8; j2++) lds[t + 256 * j2] = v[R16(j2)];
+        }
         __syncthreads();
         // ---- real-input split + magnitude (src/utils.rs:60).  Z[k] and Z[4096-k] yield X[k] AND X[4096-k]:
         // thread t pairs its bins k = t + 256 j, j < 8, with their mirrors (k = 0 pairs DC with Nyquist);
@@ -360,7 +365,9 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
             if (ABL == 2) { sq_k = v[R16(j)].x; sq_m = v[R16(j)].y; }
             else {
                 const f2 w = ABL == 6 ? mk(0.6f, 0.8f) : (j == 0 ? c_sp : cmul_pk_s(c_sp, mk(CJ, -SJ)));
-                split_pair_sq(v[R16(j)], lds[(4096 - k) & 4095], w, sq_k, sq_m);
+                // k = 0 pairs DC with itself (thread 0's own register); every other mirror is in the upper half
+                const f2 zm = lds[k == 0 ? 2048 : 4096 - k];
+                split_pair_sq(v[R16(j)], (j == 0 && t == 0) ? v[R16(0)] : zm, w, sq_k, sq_m);
             }
             m_lo[j] = mag_from_sq4(sq_k);
             m_hi[j] = mag_from_sq4(sq_m);
@@ -459,6 +466,8 @@ void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, 
     else if (abl == 11) LAUNCH_STFT(11);
     else if (abl == 12) LAUNCH_STFT(12);
     else if (abl == 13) LAUNCH_STFT(13);
+    else if (abl == 14) LAUNCH_STFT(14);
+    else if (abl == 15) LAUNCH_STFT(15);
     else if (occ == 4)
         hipLaunchKernelGGL((stft8192_kernel<0, 4>), dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs,
                            b.pfx_c, t.hann8192, t.tw8192, t.tw_p1, w.spec, w.frame_max, w.h1);
