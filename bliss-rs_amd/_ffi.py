@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblissgpu.so")
 
-OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_OOM = 0, 1, 2, 3, 4
+OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_NAN = 0, 1, 2, 3, 4, 5
 SONG_OK, SONG_TOO_SHORT = 0, 1
 METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_MAHALANOBIS = 0, 1, 2
 
@@ -37,6 +37,13 @@ SIGNATURES = {
     "blissgpu_pairwise": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp]),
     "blissgpu_pairwise_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp,
                                            C.c_uint64]),
+    "blissgpu_set_distance": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp]),
+    "blissgpu_closest_to_songs": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp]),
+    "blissgpu_song_to_song": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp]),
+    "blissgpu_set_distance_device": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp]),
+    "blissgpu_closest_to_songs_device": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp,
+                                                   _vp]),
+    "blissgpu_song_to_song_device": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp]),
     "blissgpu_feature_weights": (C.c_int, [C.c_uint32, _vp]),
     "blissgpu_malloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
     "blissgpu_free": (C.c_int, [_vp]),

@@ -33,7 +33,7 @@ int fail(int code, const char* what, const char* detail) {
 
 const char* const kKernelNames[K_COUNT] = {
     "pcm_stats_kernel", "fft512_kernel",     "onset_kernel",      "beat_kernel",   "stft8192_kernel", "tune_select_kernel",
-    "tune_pass2_kernel", "tune_final_kernel", "chroma_kernel",     "summary_kernel", "assemble_kernel", "pairwise_kernel", "synth_kernel"};
+    "tune_pass2_kernel", "tune_final_kernel", "chroma_kernel",     "summary_kernel", "assemble_kernel", "pairwise_kernel", "set_distance_kernel", "song_to_song_kernel", "synth_kernel"};
 
 struct EventPair { hipEvent_t a, b; };
 
@@ -79,6 +79,11 @@ struct blissgpu_ctx {
     DevBuf<int32_t> dbg_tuning;
     DevBuf<uint32_t> dbg_nbpms;
     uint32_t dbg_n = 0;
+    // playlist ordering scratch
+    int n_cus = 0;
+    DevBuf<uint32_t> pl_sync, pl_keys;
+    DevBuf<uint8_t> pl_tmp;
+    DevBuf<unsigned long long> pl_slots;
     Workspace last_ws{};                 // workspace carving of the last chunk (debug taps)
     std::vector<SongDesc> last_songs;    // its descriptors
     // profiling
@@ -392,6 +397,7 @@ const char* blissgpu_strerror(int code) {
         case BLISSGPU_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
         case BLISSGPU_ERR_INVALID: return "invalid argument";
         case BLISSGPU_ERR_HIP: return "HIP runtime error";
+        case BLISSGPU_ERR_NAN: return "a distance is NaN";
         case BLISSGPU_ERR_OOM: return "out of device memory";
         default: return "unknown error";
     }
@@ -408,6 +414,7 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
     HIP_TRY(hipSetDevice(device));
     blissgpu_ctx* c = new blissgpu_ctx();
     c->device = device;
+    (void)hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device);
     hipError_t se = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(BLISSGPU_ERR_HIP, "hipStreamCreate", hipGetErrorString(se)); }
     c->stream = c->own_stream;
@@ -650,6 +657,175 @@ int blissgpu_pairwise(const float* A, uint64_t n, const float* B, uint64_t m, ui
 
 int blissgpu_distance(const float* a, const float* b, uint32_t d, int metric, const float* M, float* out) {
     return blissgpu_pairwise(a, 1, b, 1, d, metric, M, out);
+}
+
+// ---- playlist ordering (src/playlist.rs:24-59, 256-326) ----
+static int playlist_args_ok(const char* who, const void* a, const void* b, const void* o, uint32_t n_seeds, uint64_t n,
+                            uint32_t d, int metric, const float* M) {
+    if (!a || !b || !o) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
+    if (d == 0 || d > 64 || metric < 0 || metric > 2) return fail(BLISSGPU_ERR_INVALID, who, "bad d / metric");
+    if (metric == BLISSGPU_METRIC_MAHALANOBIS && !M) return fail(BLISSGPU_ERR_INVALID, who, "mahalanobis needs M");
+    if (n_seeds == 0) return fail(BLISSGPU_ERR_INVALID, who, "empty seed set");
+    if (n > 0xFFFFFFFFull) return fail(BLISSGPU_ERR_INVALID, who, "more than 2^32 - 1 candidates");
+    return BLISSGPU_OK;
+}
+
+// reads the device NaN flag (synchronises the stream)
+static int nan_check(blissgpu_ctx* c, const uint32_t* d_flag, const char* who) {
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flag) return fail(BLISSGPU_ERR_NAN, who, "NaN distance (the reference panics here)");
+    return BLISSGPU_OK;
+}
+
+int blissgpu_set_distance_device(blissgpu_ctx* c, const float* d_seeds, uint32_t n_seeds, const float* d_cand, uint64_t n,
+                                 uint32_t d, int metric, const float* d_M, float* d_out) {
+    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_set_distance_device", "ctx is NULL");
+    int rc = playlist_args_ok("blissgpu_set_distance_device", d_seeds, d_cand, d_out, n_seeds, n, d, metric, d_M);
+    if (rc) return rc;
+    if (n == 0) return BLISSGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    rc = c->pl_sync.ensure(4);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->pl_sync.p, 0, 4 * sizeof(uint32_t), c->stream));
+    {
+        Prof p(c, K_SET_DISTANCE);
+        launch_set_distance(d_seeds, n_seeds, d_cand, n, d, metric, d_M, d_out, nullptr, nullptr, c->pl_sync.p + 1, c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    return BLISSGPU_OK;  // NaN distances are returned as data here, like DistanceMetric::distance
+}
+
+int blissgpu_closest_to_songs_device(blissgpu_ctx* c, const float* d_seeds, uint32_t n_seeds, const float* d_cand,
+                                     uint64_t n, uint32_t d, int metric, const float* d_M, uint32_t* d_order, float* d_dist) {
+    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_closest_to_songs_device", "ctx is NULL");
+    int rc = playlist_args_ok("blissgpu_closest_to_songs_device", d_seeds, d_cand, d_order, n_seeds, n, d, metric, d_M);
+    if (rc) return rc;
+    if (n == 0) return BLISSGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n32 = (uint32_t)n;
+    size_t tmp_bytes = 0;
+    HIP_TRY(sort_pairs_u32(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, n32, c->stream));
+    rc = c->pl_sync.ensure(4);
+    if (!rc) rc = c->pl_keys.ensure((size_t)3 * n32);  // keys in | keys out | indices in
+    if (!rc) rc = c->pl_tmp.ensure(tmp_bytes);
+    if (rc) return rc;
+    uint32_t *keys_in = c->pl_keys.p, *keys_out = keys_in + n32, *idx_in = keys_out + n32;
+    HIP_TRY(hipMemsetAsync(c->pl_sync.p, 0, 4 * sizeof(uint32_t), c->stream));
+    {
+        Prof p(c, K_SET_DISTANCE);
+        launch_set_distance(d_seeds, n_seeds, d_cand, n, d, metric, d_M, d_dist, keys_in, idx_in, c->pl_sync.p + 1, c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(sort_pairs_u32(c->pl_tmp.p, &tmp_bytes, keys_in, keys_out, idx_in, d_order, n32, c->stream));
+    return nan_check(c, c->pl_sync.p + 1, "blissgpu_closest_to_songs_device");
+}
+
+int blissgpu_song_to_song_device(blissgpu_ctx* c, const float* d_seeds, uint32_t n_seeds, const float* d_cand, uint64_t n,
+                                 uint32_t d, int metric, const float* d_M, uint32_t* d_order) {
+    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_song_to_song_device", "ctx is NULL");
+    int rc = playlist_args_ok("blissgpu_song_to_song_device", d_seeds, d_cand, d_order, n_seeds, n, d, metric, d_M);
+    if (rc) return rc;
+    if (n == 0) return BLISSGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    // one workgroup per 256 candidates up to one per CU (all workgroups must be co-resident: the kernel spins on
+    // a grid barrier); each thread then owns ceil(n / (256 G)) <= 64 candidates
+    uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)std::max(1, c->n_cus));
+    if (grid > 256) grid = 256;
+    if ((n + (uint64_t)grid * 256 - 1) / ((uint64_t)grid * 256) > 64)
+        return fail(BLISSGPU_ERR_INVALID, "blissgpu_song_to_song_device", "pool too large for one launch (> 64 candidates per thread)");
+    rc = c->pl_sync.ensure(4);
+    if (!rc) rc = c->pl_slots.ensure((size_t)2 * grid);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->pl_sync.p, 0, 4 * sizeof(uint32_t), c->stream));
+    {
+        Prof p(c, K_SONG_TO_SONG);
+        launch_song_to_song(d_seeds, n_seeds, d_cand, (uint32_t)n, d, metric, d_M, d_order, c->pl_slots.p, c->pl_sync.p, grid,
+                            c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    return nan_check(c, c->pl_sync.p + 1, "blissgpu_song_to_song_device");
+}
+
+// host-pointer wrappers: stage seeds / candidates / M, run the device form, copy the result back
+namespace {
+struct PlStage {
+    float *seeds = nullptr, *cand = nullptr, *M = nullptr;
+    void* out = nullptr;
+    float* dist = nullptr;
+    ~PlStage() { (void)hipFree(seeds); (void)hipFree(cand); (void)hipFree(M); (void)hipFree(out); (void)hipFree(dist); }
+    int up(blissgpu_ctx* c, const float* h_seeds, uint32_t n_seeds, const float* h_cand, uint64_t n, uint32_t d, int metric,
+           const float* h_M, size_t out_bytes, bool want_dist) {
+        hipError_t e = hipMalloc((void**)&seeds, (size_t)n_seeds * d * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&cand, std::max<size_t>(1, n * d) * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&out, std::max<size_t>(4, out_bytes));
+        if (e == hipSuccess && want_dist) e = hipMalloc((void**)&dist, std::max<size_t>(1, n) * sizeof(float));
+        if (e == hipSuccess && metric == BLISSGPU_METRIC_MAHALANOBIS) e = hipMalloc((void**)&M, (size_t)d * d * sizeof(float));
+        if (e != hipSuccess) return fail(BLISSGPU_ERR_OOM, "hipMalloc(playlist)", hipGetErrorString(e));
+        e = hipMemcpyAsync(seeds, h_seeds, (size_t)n_seeds * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && n) e = hipMemcpyAsync(cand, h_cand, n * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && M) e = hipMemcpyAsync(M, h_M, (size_t)d * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) return fail(BLISSGPU_ERR_HIP, "hipMemcpyAsync(playlist)", hipGetErrorString(e));
+        return BLISSGPU_OK;
+    }
+    int down(blissgpu_ctx* c, void* h_out, size_t out_bytes, float* h_dist, uint64_t n) {
+        hipError_t e = hipSuccess;
+        if (out_bytes) e = hipMemcpyAsync(h_out, out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && h_dist && n) e = hipMemcpyAsync(h_dist, dist, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(BLISSGPU_ERR_HIP, "copy back(playlist)", hipGetErrorString(e));
+        return BLISSGPU_OK;
+    }
+};
+}  // namespace
+
+int blissgpu_set_distance(const float* seeds, uint32_t n_seeds, const float* cand, uint64_t n, uint32_t d, int metric,
+                          const float* M, float* out) {
+    int rc = playlist_args_ok("blissgpu_set_distance", seeds, cand, out, n_seeds, n, d, metric, M);
+    if (rc || n == 0) return rc;
+    blissgpu_ctx* c;
+    rc = default_ctx(&c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    PlStage s;
+    rc = s.up(c, seeds, n_seeds, cand, n, d, metric, M, n * sizeof(float), false);
+    if (!rc) rc = blissgpu_set_distance_device(c, s.seeds, n_seeds, s.cand, n, d, metric, s.M, (float*)s.out);
+    if (!rc) rc = s.down(c, out, n * sizeof(float), nullptr, 0);
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
+}
+
+int blissgpu_closest_to_songs(const float* seeds, uint32_t n_seeds, const float* cand, uint64_t n, uint32_t d, int metric,
+                              const float* M, uint32_t* order, float* dist) {
+    int rc = playlist_args_ok("blissgpu_closest_to_songs", seeds, cand, order, n_seeds, n, d, metric, M);
+    if (rc || n == 0) return rc;
+    blissgpu_ctx* c;
+    rc = default_ctx(&c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    PlStage s;
+    rc = s.up(c, seeds, n_seeds, cand, n, d, metric, M, n * sizeof(uint32_t), dist != nullptr);
+    if (!rc) rc = blissgpu_closest_to_songs_device(c, s.seeds, n_seeds, s.cand, n, d, metric, s.M, (uint32_t*)s.out, s.dist);
+    if (!rc) rc = s.down(c, order, n * sizeof(uint32_t), dist, n);
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
+}
+
+int blissgpu_song_to_song(const float* seeds, uint32_t n_seeds, const float* cand, uint64_t n, uint32_t d, int metric,
+                          const float* M, uint32_t* order) {
+    int rc = playlist_args_ok("blissgpu_song_to_song", seeds, cand, order, n_seeds, n, d, metric, M);
+    if (rc || n == 0) return rc;
+    blissgpu_ctx* c;
+    rc = default_ctx(&c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    PlStage s;
+    rc = s.up(c, seeds, n_seeds, cand, n, d, metric, M, n * sizeof(uint32_t), false);
+    if (!rc) rc = blissgpu_song_to_song_device(c, s.seeds, n_seeds, s.cand, n, d, metric, s.M, (uint32_t*)s.out);
+    if (!rc) rc = s.down(c, order, n * sizeof(uint32_t), nullptr, 0);
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
 }
 
 int blissgpu_malloc(void** p, uint64_t bytes) {

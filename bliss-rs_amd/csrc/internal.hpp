@@ -89,7 +89,7 @@ enum KernelId : int {
     K_CHROMA,
     K_SUMMARY,
     K_FINALIZE,
-    K_PAIRWISE,
+    K_PAIRWISE, K_SET_DISTANCE, K_SONG_TO_SONG,
     K_SYNTH,
     K_COUNT
 };
@@ -158,6 +158,14 @@ void launch_summary(const Batch&, const Workspace&, hipStream_t);
 void launch_finalize(const Batch&, const Workspace&, uint32_t features_version, float* d_out, int32_t* dbg_tuning,
                      uint32_t* dbg_nbpms, hipStream_t);
 void launch_chroma_bank(double* bank, hipStream_t);
+// playlist ordering (kernels_playlist.hip)
+void launch_set_distance(const float* seeds, uint32_t n_seeds, const float* cand, uint64_t n, uint32_t d, int metric,
+                         const float* M, float* dist, uint32_t* keys, uint32_t* idx, uint32_t* nan_flag, hipStream_t st);
+hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                          const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, hipStream_t st);
+void launch_song_to_song(const float* seeds, uint32_t n_seeds, const float* cand, uint32_t n, uint32_t d, int metric,
+                         const float* M, uint32_t* order, unsigned long long* slots, uint32_t* sync, uint32_t grid,
+                         hipStream_t st);
 void launch_pairwise(const float* A, uint64_t n, const float* B, uint64_t m, uint32_t d, int metric, const float* M,
                      int m_is_diag, float* out, uint64_t ld_out, hipStream_t);
 void launch_synth(float* pcm, const SongDesc* songs, uint32_t n_songs, const uint32_t* pfx_e, uint32_t tiles_e,

@@ -1,0 +1,200 @@
+// kernels_playlist.hip -- playlist ordering on the device (compiled with -ffp-contract=off).
+//
+// Reference (src/playlist.rs):
+//   FunctionDistanceMetric::distance :52-58   sum over the seed set of func(seed, vector), sequential f32
+//   closest_to_songs                 :256-270 stable sort of the candidates by that distance
+//   song_to_song                     :272-326 greedy nearest-neighbour chain: argmin (first minimum) over the pool,
+//                                             remove, the emitted song becomes the only seed
+// The per-pair arithmetic is the bit-exact restatement used by the pairwise kernel (ndarray's unrolled_dot
+// order, no FMA), so orders -- including ties -- match the reference's.
+//
+// song_to_song is n dependent steps of an O(n d) scan.  One persistent launch runs all of them: the pool is
+// spread over G <= #CU workgroups (each thread owns the candidates gtid, gtid + T, ...), a step is a
+// local scan -> workgroup min -> one 8-byte slot per workgroup -> grid barrier -> every workgroup reduces the
+// G slots redundantly.  Keys are (order-preserving u32 image of the distance) << 32 | candidate index, so the
+// u64 minimum is the first minimum in pool order (Vec::remove keeps the relative order of the pool).
+#include <hipcub/hipcub.hpp>
+
+#include "device_utils.hpp"
+#include "internal.hpp"
+
+namespace bg {
+
+enum { PL_EUCLIDEAN = 0, PL_COSINE = 1, PL_MAHALANOBIS = 2 };
+constexpr int PL_DMAX = 64;
+
+// ndarray::numeric_util::unrolled_dot (8 partial sums, (p0+p4)+(p1+p5)+(p2+p6)+(p3+p7), tail sequentially)
+template <typename FX, typename FY>
+__device__ __forceinline__ float pl_udot(FX xs, FY ys, uint32_t d) {
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint32_t k = 0;
+    for (; k + 8 <= d; k += 8)
+#pragma unroll
+        for (int u = 0; u < 8; u++) p[u] = p[u] + xs(k + u) * ys(k + u);
+    float sum = 0.0f;
+    sum = sum + (p[0] + p[4]);
+    sum = sum + (p[1] + p[5]);
+    sum = sum + (p[2] + p[6]);
+    sum = sum + (p[3] + p[7]);
+    for (; k < d; k++) sum = sum + xs(k) * ys(k);
+    return sum;
+}
+
+// euclidean / cosine / mahalanobis distance of src/playlist.rs:65-79,140-142 between a (any address space)
+// and b; same evaluation order as pairwise_generic_kernel
+__device__ __forceinline__ float pl_distance(const float* a, const float* b, uint32_t d, int metric,
+                                             const float* __restrict__ M) {
+    if (metric == PL_COSINE) {
+        const float ab = pl_udot([&](uint32_t k) { return a[k]; }, [&](uint32_t k) { return b[k]; }, d);
+        const float aa = pl_udot([&](uint32_t k) { return a[k]; }, [&](uint32_t k) { return a[k]; }, d);
+        const float bb = pl_udot([&](uint32_t k) { return b[k]; }, [&](uint32_t k) { return b[k]; }, d);
+        return 1.0f - ab / (sqrtf(aa) * sqrtf(bb));
+    }
+    if (metric == PL_EUCLIDEAN) {
+        return sqrtf(pl_udot([&](uint32_t k) { return a[k] - b[k]; }, [&](uint32_t k) { return a[k] - b[k]; }, d));
+    }
+    float t[PL_DMAX];
+    for (uint32_t jj = 0; jj < d; jj++) {
+        float s = 0.0f;
+        for (uint32_t ii = 0; ii < d; ii++) s = s + (a[ii] - b[ii]) * M[ii * d + jj];
+        t[jj] = s;
+    }
+    return sqrtf(pl_udot([&](uint32_t k) { return t[k]; }, [&](uint32_t k) { return a[k] - b[k]; }, d));
+}
+
+// FunctionDistanceMetric::distance: sequential f32 sum over the seeds, in seed order
+__device__ __forceinline__ float pl_set_distance(const float* __restrict__ seeds, uint32_t n_seeds, const float* v,
+                                                 uint32_t d, int metric, const float* __restrict__ M) {
+    float acc = 0.0f;
+    for (uint32_t i = 0; i < n_seeds; i++) acc = acc + pl_distance(seeds + (size_t)i * d, v, d, metric, M);
+    return acc;
+}
+
+// order-preserving u32 image of a non-NaN float; -0.0 and +0.0 compare equal in the reference (partial_cmp /
+// n32), so both map to the image of +0.0
+__device__ __forceinline__ uint32_t f32_key(float v) {
+    if (v == 0.0f) v = 0.0f;
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// ---- distance of every candidate to the seed set (+ sort keys, + NaN flag) ----
+__global__ __launch_bounds__(256) void set_distance_kernel(const float* __restrict__ seeds, uint32_t n_seeds,
+                                                           const float* __restrict__ cand, uint64_t n, uint32_t d,
+                                                           int metric, const float* __restrict__ M,
+                                                           float* __restrict__ dist, uint32_t* __restrict__ keys,
+                                                           uint32_t* __restrict__ idx, uint32_t* __restrict__ nan_flag) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    float c[PL_DMAX];
+    for (uint32_t k = 0; k < d; k++) c[k] = cand[j * d + k];
+    const float v = pl_set_distance(seeds, n_seeds, c, d, metric, M);
+    if (dist) dist[j] = v;
+    if (keys) {
+        keys[j] = f32_key(v);
+        idx[j] = (uint32_t)j;
+    }
+    if (v != v) atomicOr(nan_flag, 1u);
+}
+
+void launch_set_distance(const float* seeds, uint32_t n_seeds, const float* cand, uint64_t n, uint32_t d, int metric,
+                         const float* M, float* dist, uint32_t* keys, uint32_t* idx, uint32_t* nan_flag, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(set_distance_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, seeds, n_seeds, cand, n,
+                       d, metric, M, dist, keys, idx, nan_flag);
+}
+
+// stable LSD radix sort of (key, index) pairs: equal distances keep their original order, like
+// slice::sort_by_cached_key
+hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                          const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, hipStream_t st) {
+    return hipcub::DeviceRadixSort::SortPairs(tmp, *tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 32, st);
+}
+
+// ---- song_to_song: one persistent launch, grid barrier per step ----
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, WAVE);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void song_to_song_kernel(const float* __restrict__ seeds, uint32_t n_seeds,
+                                                           const float* __restrict__ cand, uint32_t n, uint32_t d,
+                                                           int metric, const float* __restrict__ M,
+                                                           uint32_t* __restrict__ order,
+                                                           unsigned long long* slots,  // [2][gridDim.x]
+                                                           uint32_t* sync) {           // [0] barrier, [1] NaN flag
+    __shared__ unsigned long long red[4];
+    __shared__ unsigned long long s_win;
+    __shared__ float s_cur[PL_DMAX];
+    const uint32_t G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
+    const uint32_t T = G * 256, gtid = wg * 256 + tid;
+    const int lane = lane_id(), wave = wave_id();
+    const uint32_t per = (n + T - 1) / T;  // candidates per thread (<= 64, checked by the host)
+    unsigned long long alive = 0;
+    for (uint32_t k = 0; k < per; k++)
+        if (gtid + k * T < n) alive |= 1ull << k;
+
+    for (uint32_t step = 0; step < n; step++) {
+        // ---- local scan: the metric is the seed set at step 0, the previously emitted song afterwards ----
+        unsigned long long best = ~0ull;
+        bool saw_nan = false;
+        for (uint32_t k = 0; k < per; k++) {
+            if (!((alive >> k) & 1ull)) continue;
+            const uint32_t j = gtid + k * T;
+            float c[PL_DMAX];
+            for (uint32_t q = 0; q < d; q++) c[q] = cand[(size_t)j * d + q];
+            const float v = (step == 0) ? pl_set_distance(seeds, n_seeds, c, d, metric, M)
+                                        : (0.0f + pl_distance(s_cur, c, d, metric, M));
+            if (v != v) saw_nan = true;
+            const unsigned long long key = ((unsigned long long)f32_key(v) << 32) | j;
+            best = key < best ? key : best;
+        }
+        if (saw_nan) __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        best = wave_min_u64(best);
+        if (lane == 0) red[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = red[0];
+            for (int w = 1; w < 4; w++) b = red[w] < b ? red[w] : b;
+            __hip_atomic_store(&slots[(size_t)(step & 1) * G + wg], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // grid barrier: monotonically increasing arrival counter (release on arrive, acquire on leave)
+            __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t target = G * (step + 1);
+            while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        // ---- every workgroup reduces the G slots (G <= 256: one per thread) ----
+        unsigned long long w = ~0ull;
+        if (tid < G) w = __hip_atomic_load(&slots[(size_t)(step & 1) * G + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w = wave_min_u64(w);
+        if (lane == 0) red[wave] = w;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = red[0];
+            for (int q = 1; q < 4; q++) b = red[q] < b ? red[q] : b;
+            s_win = b;
+        }
+        __syncthreads();
+        if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // NaN: uniform exit
+        const uint32_t win = (uint32_t)(s_win & 0xFFFFFFFFull);
+        if (wg == 0 && tid == 0) order[step] = win;
+        if (win % T == gtid) alive &= ~(1ull << (win / T));
+        if (tid < d) s_cur[tid] = cand[(size_t)win * d + tid];
+        __syncthreads();
+    }
+}
+
+void launch_song_to_song(const float* seeds, uint32_t n_seeds, const float* cand, uint32_t n, uint32_t d, int metric,
+                         const float* M, uint32_t* order, unsigned long long* slots, uint32_t* sync, uint32_t grid,
+                         hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(song_to_song_kernel, dim3(grid), dim3(256), 0, st, seeds, n_seeds, cand, n, d, metric, M, order,
+                       slots, sync);
+}
+
+}  // namespace bg

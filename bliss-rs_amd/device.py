@@ -116,6 +116,59 @@ class Context:
                                                     d, _METRICS[metric], Mp, C.c_void_p(out.data_ptr()), out.stride(0)))
         return out
 
+    # ---- playlist ordering on device-resident feature matrices (src/playlist.rs:24-59, 256-326) ----
+    def _pl_args(self, seeds, cand, M):
+        torch = self.torch
+        assert seeds.is_cuda and cand.is_cuda and seeds.dtype == torch.float32 and cand.dtype == torch.float32
+        seeds, cand = seeds.contiguous(), cand.contiguous()
+        if seeds.dim() == 1:
+            seeds = seeds[None, :]
+        Mp = None
+        if M is not None:
+            M = M.contiguous()
+            Mp = C.c_void_p(M.data_ptr())
+        return seeds, cand, M, Mp
+
+    def set_distance(self, seeds, cand, metric: str = "euclidean", M=None):
+        """FunctionDistanceMetric::distance of every candidate row to the seed set."""
+        from .playlist import _METRICS
+
+        seeds, cand, M, Mp = self._pl_args(seeds, cand, M)
+        out = self.torch.empty((cand.shape[0],), dtype=self.torch.float32, device=cand.device)
+        _ffi.check(self._L.blissgpu_set_distance_device(self._h, C.c_void_p(seeds.data_ptr()), seeds.shape[0],
+                                                        C.c_void_p(cand.data_ptr()), cand.shape[0], cand.shape[1],
+                                                        _METRICS[metric], Mp, C.c_void_p(out.data_ptr())))
+        self.synchronize()  # the launch is on the context's stream, not torch's current stream
+        return out
+
+    def closest_to_songs(self, seeds, cand, metric: str = "euclidean", M=None, return_distances=False):
+        """Indices of the candidates sorted (stably) by distance to the seed set (int64 tensor)."""
+        from .playlist import _METRICS
+
+        torch = self.torch
+        seeds, cand, M, Mp = self._pl_args(seeds, cand, M)
+        n = cand.shape[0]
+        order = torch.empty((n,), dtype=torch.int32, device=cand.device)
+        dist = torch.empty((n,), dtype=torch.float32, device=cand.device)
+        _ffi.check(self._L.blissgpu_closest_to_songs_device(self._h, C.c_void_p(seeds.data_ptr()), seeds.shape[0],
+                                                            C.c_void_p(cand.data_ptr()), n, cand.shape[1], _METRICS[metric],
+                                                            Mp, C.c_void_p(order.data_ptr()), C.c_void_p(dist.data_ptr())))
+        order = order.to(torch.int64)
+        return (order, dist) if return_distances else order
+
+    def song_to_song(self, seeds, cand, metric: str = "euclidean", M=None):
+        """Greedy nearest-neighbour chain over the candidates (int64 index tensor)."""
+        from .playlist import _METRICS
+
+        torch = self.torch
+        seeds, cand, M, Mp = self._pl_args(seeds, cand, M)
+        n = cand.shape[0]
+        order = torch.empty((n,), dtype=torch.int32, device=cand.device)
+        _ffi.check(self._L.blissgpu_song_to_song_device(self._h, C.c_void_p(seeds.data_ptr()), seeds.shape[0],
+                                                        C.c_void_p(cand.data_ptr()), n, cand.shape[1], _METRICS[metric], Mp,
+                                                        C.c_void_p(order.data_ptr())))
+        return order.to(torch.int64)
+
     # ---- profiling ----
     def profile_enable(self, on: bool = True):
         _ffi.check(self._L.blissgpu_profile_enable(self._h, int(on)))

@@ -31,6 +31,7 @@ extern "C" {
 #define BLISSGPU_ERR_INVALID 2        /* bad argument (NULL pointer, unknown features_version/metric, d > 64) */
 #define BLISSGPU_ERR_HIP 3            /* a HIP runtime call failed; see blissgpu_last_error() */
 #define BLISSGPU_ERR_OOM 4            /* workspace allocation failed */
+#define BLISSGPU_ERR_NAN 5            /* a distance is NaN: the reference panics there (n32(), argmin().unwrap()) */
 
 /* ---- per-song status, maps 1:1 onto BlissError (src/lib.rs:236-252) ---- */
 #define BLISSGPU_SONG_OK 0
@@ -94,6 +95,34 @@ int blissgpu_pairwise(const float *A, uint64_t n, const float *B, uint64_t m, ui
 /* Device-resident form; ld_out is the row pitch of d_out in elements (>= m).  Asynchronous. */
 int blissgpu_pairwise_device(blissgpu_ctx *ctx, const float *d_A, uint64_t n, const float *d_B, uint64_t m,
                              uint32_t d, int metric, const float *d_M, float *d_out, uint64_t ld_out);
+
+/* ---- playlist ordering (src/playlist.rs:24-59, 256-326) ----
+ * A "song" is a row of a feature matrix; results are index permutations into the candidate matrix.
+ * The metric built from a set of vectors is FunctionDistanceMetric (src/playlist.rs:36-59): the sequential
+ * f32 sum over the set of func(vector_of_the_set, candidate), func = one of the three metrics above.
+ * A NaN distance returns BLISSGPU_ERR_NAN (the reference panics: n32() / argmin().unwrap()). */
+
+/* FunctionDistanceMetric::distance for every candidate: out[j] = sum_i metric(seeds[i], cand[j]). */
+int blissgpu_set_distance(const float *seeds, uint32_t n_seeds, const float *cand, uint64_t n, uint32_t d, int metric,
+                          const float *M, float *out);
+/* closest_to_songs (src/playlist.rs:256-270): order[k] = index of the k-th closest candidate to the seed set
+ * (stable: equal distances keep the candidates' order, like sort_by_cached_key); dist (may be NULL) receives
+ * the distances in candidate order. */
+int blissgpu_closest_to_songs(const float *seeds, uint32_t n_seeds, const float *cand, uint64_t n, uint32_t d,
+                              int metric, const float *M, uint32_t *order, float *dist);
+/* song_to_song (src/playlist.rs:272-326): greedy nearest-neighbour chain.  order[0] = the candidate closest to the
+ * seed set, order[k] = the remaining candidate closest to candidate order[k-1] (first minimum in pool order). */
+int blissgpu_song_to_song(const float *seeds, uint32_t n_seeds, const float *cand, uint64_t n, uint32_t d, int metric,
+                          const float *M, uint32_t *order);
+/* Device-resident forms (all pointers are HIP device pointers; asynchronous except for the NaN check, which
+ * synchronises the context's stream before returning). */
+int blissgpu_set_distance_device(blissgpu_ctx *ctx, const float *d_seeds, uint32_t n_seeds, const float *d_cand,
+                                 uint64_t n, uint32_t d, int metric, const float *d_M, float *d_out);
+int blissgpu_closest_to_songs_device(blissgpu_ctx *ctx, const float *d_seeds, uint32_t n_seeds, const float *d_cand,
+                                     uint64_t n, uint32_t d, int metric, const float *d_M, uint32_t *d_order,
+                                     float *d_dist);
+int blissgpu_song_to_song_device(blissgpu_ctx *ctx, const float *d_seeds, uint32_t n_seeds, const float *d_cand,
+                                 uint64_t n, uint32_t d, int metric, const float *d_M, uint32_t *d_order);
 
 /* FeaturesVersion::feature_weights (src/lib.rs:168-173, 209-234): d x d row-major diagonal matrix. */
 int blissgpu_feature_weights(uint32_t features_version, float *M);

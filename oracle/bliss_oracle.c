@@ -1210,6 +1210,146 @@ void bo_pairwise(const float *A, size_t n, const float *B, size_t m, size_t d, i
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Playlist ordering: src/playlist.rs:24-59 (FunctionDistanceMetric), :173-221
+ * (variance_based_weight_matrix), :256-270 (closest_to_songs), :272-326 (song_to_song),
+ * :367-402 (dedup_playlist_custom_distance).  Songs are rows of feature matrices; the results are
+ * index permutations / kept-index lists.
+ * ---------------------------------------------------------------------------------------- */
+static float pw_single(const float *a, const float *b, const float *M, size_t d, int metric) {
+    if (metric == 0) return bo_euclidean_distance(a, b, d);
+    if (metric == 1) return bo_cosine_distance(a, b, d);
+    return bo_mahalanobis_distance(a, b, M, d);
+}
+
+/* FunctionDistanceMetric::distance (:52-58): self.state.iter().map(|v| func(v, vector)).sum::<f32>() */
+float bo_set_distance(const float *seeds, size_t n_seeds, const float *v, size_t d, int metric, const float *M) {
+    float acc = 0.0f;
+    for (size_t i = 0; i < n_seeds; i++) acc += pw_single(seeds + i * d, v, M, d, metric);
+    return acc;
+}
+
+/* closest_to_songs (:256-270): sort_by_cached_key(n32(distance to the seed set)) -- a STABLE sort;
+ * n32 panics on NaN => return -1.  order[k] = index of the k-th song of the playlist. */
+int bo_closest_to_songs(const float *seeds, size_t n_seeds, const float *cand, size_t n, size_t d, int metric,
+                        const float *M, uint32_t *order, float *dist_out) {
+    float *key = (float *)malloc(sizeof(float) * (n ? n : 1));
+    uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    int rc = 0;
+    for (size_t j = 0; j < n; j++) {
+        key[j] = bo_set_distance(seeds, n_seeds, cand + j * d, d, metric, M);
+        if (key[j] != key[j]) rc = -1;
+        order[j] = (uint32_t)j;
+    }
+    if (rc == 0) {  /* bottom-up merge sort: stable, like slice::sort_by_cached_key */
+        for (size_t w = 1; w < n; w *= 2) {
+            for (size_t lo = 0; lo < n; lo += 2 * w) {
+                size_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+                size_t i = lo, j = mid, k = lo;
+                while (i < mid && j < hi) tmp[k++] = (key[order[j]] < key[order[i]]) ? order[j++] : order[i++];
+                while (i < mid) tmp[k++] = order[i++];
+                while (j < hi) tmp[k++] = order[j++];
+            }
+            memcpy(order, tmp, sizeof(uint32_t) * n);
+        }
+    }
+    if (dist_out) memcpy(dist_out, key, sizeof(float) * n);
+    free(key); free(tmp);
+    return rc;
+}
+
+/* song_to_song (:272-326): greedy nearest-neighbour chain.  The first metric is built from all the
+ * initial songs, every later one from the single song just emitted; `distances.argmin()`
+ * (ndarray-stats: first minimum, Err on NaN => -1) over the pool in its current order, and
+ * Vec::remove keeps the relative order of the rest. */
+int bo_song_to_song(const float *seeds, size_t n_seeds, const float *cand, size_t n, size_t d, int metric,
+                    const float *M, uint32_t *order) {
+    uint32_t *pool = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    float *cur = (float *)malloc(sizeof(float) * (n_seeds > 1 ? n_seeds : 1) * d);
+    size_t n_cur = n_seeds, n_pool = n;
+    memcpy(cur, seeds, sizeof(float) * n_seeds * d);
+    for (size_t j = 0; j < n; j++) pool[j] = (uint32_t)j;
+    int rc = 0;
+    for (size_t step = 0; step < n && rc == 0; step++) {
+        size_t best = 0;
+        float best_d = 0.0f;
+        for (size_t j = 0; j < n_pool; j++) {
+            const float dj = bo_set_distance(cur, n_cur, cand + (size_t)pool[j] * d, d, metric, M);
+            if (dj != dj) { rc = -1; break; }
+            if (j == 0 || dj < best_d) { best = j; best_d = dj; }
+        }
+        if (rc) break;
+        const uint32_t idx = pool[best];
+        memmove(pool + best, pool + best + 1, sizeof(uint32_t) * (n_pool - best - 1));
+        n_pool--;
+        order[step] = idx;
+        memcpy(cur, cand + (size_t)idx * d, sizeof(float) * d);
+        n_cur = 1;
+    }
+    free(pool); free(cur);
+    return rc;
+}
+
+/* dedup_playlist_custom_distance (:367-402): s1 absorbs the following songs while
+ * n32(distance(s1, s2)) < threshold or (same_meta(s1, s2)); same_meta[i*n + j] (may be NULL) says
+ * whether songs i and j have the same non-empty title and artist.  Returns the number kept. */
+long bo_dedup_playlist(const float *songs, size_t n, size_t d, int metric, const float *M, float threshold,
+                       const uint8_t *same_meta, uint32_t *kept) {
+    size_t n_kept = 0, i = 0;
+    while (i < n) {
+        size_t j = i + 1;
+        while (j < n) {
+            const float dist = bo_set_distance(songs + i * d, 1, songs + j * d, d, metric, M);
+            if (dist != dist) return -1;
+            const int same = (dist < threshold) || (same_meta && same_meta[i * n + j]);
+            if (!same) break;
+            j++;
+        }
+        kept[n_kept++] = (uint32_t)i;
+        i = j;
+    }
+    return (long)n_kept;
+}
+
+/* variance_based_weight_matrix (:173-221): 0 ok, 1 "seeds must contain more than one element",
+ * 2 "seed feature vectors must not be empty" */
+int bo_variance_weight_matrix(const float *seeds, size_t n_seeds, size_t d, float *m) {
+    if (n_seeds < 2) return 1;
+    if (d == 0) return 2;
+    const float ns = (float)n_seeds;
+    float *mean = (float *)calloc(d, sizeof(float)), *var = (float *)calloc(d, sizeof(float));
+    for (size_t i = 0; i < n_seeds; i++)
+        for (size_t k = 0; k < d; k++) mean[k] += seeds[i * d + k];
+    for (size_t k = 0; k < d; k++) mean[k] /= ns;
+    for (size_t i = 0; i < n_seeds; i++)
+        for (size_t k = 0; k < d; k++) {
+            const float diff = seeds[i * d + k] - mean[k];
+            var[k] = var[k] + diff * diff;
+        }
+    float sum = 0.0f;
+    for (size_t k = 0; k < d; k++) {
+        var[k] /= ns;
+        var[k] = 1.0f / (var[k] + 1e-6f);  /* weights */
+    }
+    /* ndarray sum(): unrolled 8-lane pairwise for contiguous data -- same reduction as unrolled_dot's */
+    {
+        float p[8] = {0};
+        size_t k = 0;
+        for (; k + 8 <= d; k += 8)
+            for (int u = 0; u < 8; u++) p[u] += var[k + u];
+        sum += (p[0] + p[4]);
+        sum += (p[1] + p[5]);
+        sum += (p[2] + p[6]);
+        sum += (p[3] + p[7]);
+        for (; k < d; k++) sum += var[k];
+    }
+    const float scale = (float)d / sum;
+    memset(m, 0, sizeof(float) * d * d);
+    for (size_t k = 0; k < d; k++) m[k * d + k] = var[k] * scale;
+    free(mean); free(var);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Synthetic white noise (bench/test input, not from the reference): Philox4x32-10.
  * ---------------------------------------------------------------------------------------- */
 static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t r[4]) {

@@ -102,6 +102,16 @@ void bo_feature_weights(uint32_t features_version, float *m /* d*d */);
 void bo_pairwise(const float *A, size_t n, const float *B, size_t m, size_t d, int metric /*0 euclid,1 cosine,2 mahalanobis*/,
                  const float *M, float *out /* n*m */, uint32_t n_threads);
 
+/* ---- playlist ordering, src/playlist.rs:24-59, 173-221, 256-326, 367-402 ---- */
+float bo_set_distance(const float *seeds, size_t n_seeds, const float *v, size_t d, int metric, const float *M);
+int bo_closest_to_songs(const float *seeds, size_t n_seeds, const float *cand, size_t n, size_t d, int metric,
+                        const float *M, uint32_t *order /* n */, float *dist_out /* n or NULL */);
+int bo_song_to_song(const float *seeds, size_t n_seeds, const float *cand, size_t n, size_t d, int metric,
+                    const float *M, uint32_t *order /* n */);
+long bo_dedup_playlist(const float *songs, size_t n, size_t d, int metric, const float *M, float threshold,
+                       const uint8_t *same_meta /* n*n or NULL */, uint32_t *kept /* n */);
+int bo_variance_weight_matrix(const float *seeds, size_t n_seeds, size_t d, float *m /* d*d */);
+
 /* ---- bench/test input generator (not part of the reference): Philox4x32-10 white noise,
  * uniform [-0.5, 0.5), key = (0x5EED0000 + song_index, 0), counter = sample_index / 4 ---- */
 void bo_white_noise(uint32_t song_index, size_t n, float *out);

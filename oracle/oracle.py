@@ -72,6 +72,12 @@ def lib():
             "bo_mahalanobis_distance": (C.c_float, [f32p, f32p, f32p, sz]),
             "bo_feature_weights": (None, [C.c_uint32, f32p]),
             "bo_pairwise": (None, [f32p, sz, f32p, sz, sz, C.c_int, f32p, f32p, C.c_uint32]),
+            "bo_set_distance": (C.c_float, [f32p, sz, f32p, sz, C.c_int, f32p]),
+            "bo_closest_to_songs": (C.c_int, [f32p, sz, f32p, sz, sz, C.c_int, f32p, C.POINTER(C.c_uint32), f32p]),
+            "bo_song_to_song": (C.c_int, [f32p, sz, f32p, sz, sz, C.c_int, f32p, C.POINTER(C.c_uint32)]),
+            "bo_dedup_playlist": (C.c_long, [f32p, sz, sz, C.c_int, f32p, C.c_float, C.POINTER(C.c_uint8),
+                                             C.POINTER(C.c_uint32)]),
+            "bo_variance_weight_matrix": (C.c_int, [f32p, sz, sz, f32p]),
             "bo_white_noise": (None, [C.c_uint32, sz, f32p]),
             "bo_set_fft_double": (None, [C.c_int]),
         }
@@ -383,6 +389,69 @@ def pairwise(A, B, metric="euclidean", M=None, n_threads=1):
     lib().bo_pairwise(_p(A, C.c_float), A.shape[0], _p(B, C.c_float), B.shape[0], A.shape[1], code, Mp,
                       _p(out, C.c_float), n_threads)
     return out
+
+
+# ---- playlist ordering (src/playlist.rs:24-59, 173-221, 256-326, 367-402) ----
+_METRIC = {"euclidean": 0, "cosine": 1, "mahalanobis": 2}
+
+
+def _mp(M):
+    return _p(_f32(M), C.c_float) if M is not None else None
+
+
+def set_distance(seeds, v, metric="euclidean", M=None):
+    seeds, v = _f32(np.atleast_2d(seeds)), _f32(v)
+    return float(lib().bo_set_distance(_p(seeds, C.c_float), seeds.shape[0], _p(v, C.c_float), v.shape[0],
+                                       _METRIC[metric], _mp(M)))
+
+
+def closest_to_songs(seeds, cand, metric="euclidean", M=None):
+    """-> (order, distances); raises on NaN like n32()"""
+    seeds, cand = _f32(np.atleast_2d(seeds)), _f32(np.atleast_2d(cand))
+    n, d = cand.shape
+    order, dist = np.empty(n, np.uint32), np.empty(n, np.float32)
+    rc = lib().bo_closest_to_songs(_p(seeds, C.c_float), seeds.shape[0], _p(cand, C.c_float), n, d, _METRIC[metric],
+                                   _mp(M), _p(order, C.c_uint32), _p(dist, C.c_float))
+    if rc:
+        raise ValueError("NaN distance")
+    return order, dist
+
+
+def song_to_song(seeds, cand, metric="euclidean", M=None):
+    seeds, cand = _f32(np.atleast_2d(seeds)), _f32(np.atleast_2d(cand))
+    n, d = cand.shape
+    order = np.empty(n, np.uint32)
+    rc = lib().bo_song_to_song(_p(seeds, C.c_float), seeds.shape[0], _p(cand, C.c_float), n, d, _METRIC[metric], _mp(M),
+                               _p(order, C.c_uint32))
+    if rc:
+        raise ValueError("NaN distance")
+    return order
+
+
+def dedup_playlist(songs, threshold=0.05, metric="euclidean", M=None, same_meta=None):
+    songs = _f32(np.atleast_2d(songs))
+    n, d = songs.shape
+    kept = np.empty(max(n, 1), np.uint32)
+    sm = None
+    if same_meta is not None:
+        same_meta = np.ascontiguousarray(same_meta, dtype=np.uint8)
+        sm = _p(same_meta, C.c_uint8)
+    k = lib().bo_dedup_playlist(_p(songs, C.c_float), n, d, _METRIC[metric], _mp(M), threshold, sm, _p(kept, C.c_uint32))
+    if k < 0:
+        raise ValueError("NaN distance")
+    return kept[:k].copy()
+
+
+def variance_based_weight_matrix(seeds):
+    seeds = _f32(np.atleast_2d(seeds))
+    n, d = seeds.shape
+    m = np.empty((d, d), np.float32)
+    rc = lib().bo_variance_weight_matrix(_p(seeds, C.c_float), n, d, _p(m, C.c_float))
+    if rc == 1:
+        raise ValueError("seeds must contain more than one element")
+    if rc == 2:
+        raise ValueError("seed feature vectors must not be empty")
+    return m
 
 
 def white_noise(song_index, n):
