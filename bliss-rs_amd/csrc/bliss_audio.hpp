@@ -11,6 +11,7 @@
 //   bliss::Decoder (decode / song_from_path / analyze_paths)   src/song/decoder.rs:115-333
 //   bliss::euclidean_distance / cosine_distance / mahalanobis_distance   src/playlist.rs:65-142
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <functional>
@@ -211,5 +212,129 @@ class Decoder {
         return out;
     }
 };
+
+// ---- playlist ordering (src/playlist.rs:24-59, 173-221, 256-402); distances are evaluated on the GPU ----
+// A metric builder names one of the device metrics (the reference's `&dyn DistanceMetricBuilder` implemented by the
+// plain distance functions, src/playlist.rs:41-59); the metric it builds from a set of vectors is the sum of the
+// distances to each vector of the set.
+struct MetricBuilder {
+    int metric = BLISSGPU_METRIC_EUCLIDEAN;
+    std::vector<float> m;  // d x d row-major for MAHALANOBIS
+    const float* mptr() const { return m.empty() ? nullptr : m.data(); }
+};
+inline MetricBuilder euclidean_builder() { return {BLISSGPU_METRIC_EUCLIDEAN, {}}; }
+inline MetricBuilder cosine_builder() { return {BLISSGPU_METRIC_COSINE, {}}; }
+inline MetricBuilder mahalanobis_builder(std::vector<float> m) { return {BLISSGPU_METRIC_MAHALANOBIS, std::move(m)}; }
+
+inline void check_ordering(int rc) {  // n32() / argmin().unwrap() panic on NaN in the reference
+    if (rc == BLISSGPU_ERR_NAN) throw std::domain_error("NaN distance");
+    check(rc);
+}
+
+template <typename T>
+const Song& as_song(const T& s) { return s; }          // AsRef<Song>: specialise for wrapper types
+template <typename T>
+const Song& as_song(T* const& s) { return as_song(*s); }
+
+template <typename T>
+std::vector<float> feature_matrix(const std::vector<T>& songs, size_t& d) {
+    std::vector<float> x;
+    d = songs.empty() ? 0 : as_song(songs[0]).analysis.as_vec().size();
+    for (const auto& s : songs) {
+        const auto& v = as_song(s).analysis.as_vec();
+        if (v.size() != d) throw std::logic_error("Mismatched features version between two songs or analysis");
+        x.insert(x.end(), v.begin(), v.end());
+    }
+    return x;
+}
+
+// closest_to_songs (src/playlist.rs:256-270)
+template <typename T>
+std::vector<T> closest_to_songs(const std::vector<T>& initial_songs, const std::vector<T>& candidate_songs, const MetricBuilder& mb) {
+    if (candidate_songs.empty()) return {};
+    size_t d = 0, ds = 0;
+    const auto x = feature_matrix(candidate_songs, d);
+    const auto s = feature_matrix(initial_songs, ds);
+    std::vector<uint32_t> order(candidate_songs.size());
+    check_ordering(blissgpu_closest_to_songs(s.data(), (uint32_t)initial_songs.size(), x.data(), candidate_songs.size(), (uint32_t)d,
+                                             mb.metric, mb.mptr(), order.data(), nullptr));
+    std::vector<T> out;
+    for (uint32_t i : order) out.push_back(candidate_songs[i]);
+    return out;
+}
+
+// song_to_song (src/playlist.rs:272-326)
+template <typename T>
+std::vector<T> song_to_song(const std::vector<T>& initial_songs, const std::vector<T>& candidate_songs, const MetricBuilder& mb) {
+    if (candidate_songs.empty()) return {};
+    size_t d = 0, ds = 0;
+    const auto x = feature_matrix(candidate_songs, d);
+    const auto s = feature_matrix(initial_songs, ds);
+    std::vector<uint32_t> order(candidate_songs.size());
+    check_ordering(blissgpu_song_to_song(s.data(), (uint32_t)initial_songs.size(), x.data(), candidate_songs.size(), (uint32_t)d,
+                                         mb.metric, mb.mptr(), order.data()));
+    std::vector<T> out;
+    for (uint32_t i : order) out.push_back(candidate_songs[i]);
+    return out;
+}
+
+// dedup_playlist_custom_distance / dedup_playlist (src/playlist.rs:343-402)
+template <typename T>
+std::vector<T> dedup_playlist_custom_distance(const std::vector<T>& playlist, std::optional<float> distance_threshold, const MetricBuilder& mb) {
+    const float thr = distance_threshold.value_or(0.05f);
+    size_t d = 0;
+    const auto x = feature_matrix(playlist, d);
+    const size_t n = playlist.size(), window = 64;
+    std::vector<T> out;
+    std::vector<float> dist(window);
+    size_t i = 0;
+    while (i < n) {
+        size_t j = i + 1;
+        bool stopped = false;
+        while (j < n && !stopped) {
+            const size_t hi = std::min(n, j + window);
+            check(blissgpu_set_distance(x.data() + i * d, 1, x.data() + j * d, hi - j, (uint32_t)d, mb.metric, mb.mptr(), dist.data()));
+            size_t k = j;
+            for (; k < hi; k++) {
+                const float dk = dist[k - j];
+                if (dk != dk) throw std::domain_error("NaN distance");
+                const Song &a = as_song(playlist[i]), &b = as_song(playlist[k]);
+                const bool same = dk < thr || (a.title && b.title && a.artist && b.artist && *a.title == *b.title && *a.artist == *b.artist);
+                if (!same) { stopped = true; break; }
+            }
+            j = k;
+        }
+        out.push_back(playlist[i]);
+        i = j;
+    }
+    return out;
+}
+template <typename T>
+std::vector<T> dedup_playlist(const std::vector<T>& playlist, std::optional<float> distance_threshold) {
+    return dedup_playlist_custom_distance(playlist, distance_threshold, euclidean_builder());
+}
+
+// variance_based_weight_matrix (src/playlist.rs:173-221): d x d row-major; host arithmetic in the reference's order
+inline std::vector<float> variance_based_weight_matrix(const std::vector<std::vector<float>>& seeds) {
+    if (seeds.size() < 2) throw ProviderError("seeds must contain more than one element");
+    const size_t n = seeds[0].size();
+    if (n == 0) throw ProviderError("seed feature vectors must not be empty");
+    for (const auto& s : seeds) if (s.size() != n) throw ProviderError("all seed feature vectors must have the same length");
+    const float ns = (float)seeds.size();
+    std::vector<float> mean(n, 0.0f), var(n, 0.0f);
+    for (const auto& s : seeds) for (size_t k = 0; k < n; k++) mean[k] = mean[k] + s[k];
+    for (size_t k = 0; k < n; k++) mean[k] = mean[k] / ns;
+    for (const auto& s : seeds) for (size_t k = 0; k < n; k++) { const float diff = s[k] - mean[k]; var[k] = var[k] + diff * diff; }
+    for (size_t k = 0; k < n; k++) { var[k] = var[k] / ns; var[k] = 1.0f / (var[k] + 1e-6f); }
+    float p[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sum = 0.0f;  // ndarray sum(): unrolled_fold
+    size_t k = 0;
+    for (; k + 8 <= n; k += 8) for (int u = 0; u < 8; u++) p[u] = p[u] + var[k + u];
+    sum = sum + (p[0] + p[4]); sum = sum + (p[1] + p[5]); sum = sum + (p[2] + p[6]); sum = sum + (p[3] + p[7]);
+    for (; k < n; k++) sum = sum + var[k];
+    const float scale = (float)n / sum;
+    std::vector<float> m(n * n, 0.0f);
+    for (size_t q = 0; q < n; q++) m[q * n + q] = var[q] * scale;
+    return m;
+}
 
 }  // namespace bliss

@@ -121,8 +121,12 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
+// PER > 0: every thread keeps its PER candidates (D features each) in registers for the whole chain, so a step
+// touches memory only for the G slots and the winner's row.  PER == 0: generic path, candidates re-read from
+// L2 / MALL every step (any d <= 64, up to 64 candidates per thread).
+template <int D, int PER>
 __global__ __launch_bounds__(256) void song_to_song_kernel(const float* __restrict__ seeds, uint32_t n_seeds,
-                                                           const float* __restrict__ cand, uint32_t n, uint32_t d,
+                                                           const float* __restrict__ cand, uint32_t n, uint32_t d_rt,
                                                            int metric, const float* __restrict__ M,
                                                            uint32_t* __restrict__ order,
                                                            unsigned long long* slots,  // [2][gridDim.x]
@@ -130,28 +134,47 @@ __global__ __launch_bounds__(256) void song_to_song_kernel(const float* __restri
     __shared__ unsigned long long red[4];
     __shared__ unsigned long long s_win;
     __shared__ float s_cur[PL_DMAX];
+    const uint32_t d = PER > 0 ? (uint32_t)D : d_rt;
     const uint32_t G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
     const uint32_t T = G * 256, gtid = wg * 256 + tid;
     const int lane = lane_id(), wave = wave_id();
-    const uint32_t per = (n + T - 1) / T;  // candidates per thread (<= 64, checked by the host)
+    const uint32_t per = PER > 0 ? (uint32_t)PER : (n + T - 1) / T;  // candidates per thread (<= 64, checked by the host)
     unsigned long long alive = 0;
     for (uint32_t k = 0; k < per; k++)
         if (gtid + k * T < n) alive |= 1ull << k;
+    float mine[PER > 0 ? PER : 1][PER > 0 ? D : 1];
+    if (PER > 0) {
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const uint32_t j = gtid + (uint32_t)k * T;
+#pragma unroll
+            for (int q = 0; q < D; q++) mine[k][q] = (j < n) ? cand[(size_t)j * D + q] : 0.0f;
+        }
+    }
 
     for (uint32_t step = 0; step < n; step++) {
         // ---- local scan: the metric is the seed set at step 0, the previously emitted song afterwards ----
         unsigned long long best = ~0ull;
         bool saw_nan = false;
-        for (uint32_t k = 0; k < per; k++) {
-            if (!((alive >> k) & 1ull)) continue;
-            const uint32_t j = gtid + k * T;
-            float c[PL_DMAX];
-            for (uint32_t q = 0; q < d; q++) c[q] = cand[(size_t)j * d + q];
+        auto visit = [&](const float* c, uint32_t j) {
             const float v = (step == 0) ? pl_set_distance(seeds, n_seeds, c, d, metric, M)
                                         : (0.0f + pl_distance(s_cur, c, d, metric, M));
             if (v != v) saw_nan = true;
             const unsigned long long key = ((unsigned long long)f32_key(v) << 32) | j;
             best = key < best ? key : best;
+        };
+        if (PER > 0) {
+#pragma unroll
+            for (int k = 0; k < PER; k++)
+                if ((alive >> k) & 1ull) visit(mine[k], gtid + (uint32_t)k * T);
+        } else {
+            for (uint32_t k = 0; k < per; k++) {
+                if (!((alive >> k) & 1ull)) continue;
+                const uint32_t j = gtid + k * T;
+                float c[PL_DMAX];
+                for (uint32_t q = 0; q < d; q++) c[q] = cand[(size_t)j * d + q];
+                visit(c, j);
+            }
         }
         if (saw_nan) __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         best = wave_min_u64(best);
@@ -161,11 +184,13 @@ __global__ __launch_bounds__(256) void song_to_song_kernel(const float* __restri
             unsigned long long b = red[0];
             for (int w = 1; w < 4; w++) b = red[w] < b ? red[w] : b;
             __hip_atomic_store(&slots[(size_t)(step & 1) * G + wg], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // grid barrier: monotonically increasing arrival counter (release on arrive, acquire on leave)
+            // grid barrier: monotonically increasing arrival counter; release on arrive, relaxed polling and ONE
+            // acquire fence on leave (an acquire per poll would invalidate the caches on every iteration)
             __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t target = G * (step + 1);
-            while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
+            while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
                 __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
         // ---- every workgroup reduces the G slots (G <= 256: one per thread) ----
@@ -193,8 +218,17 @@ void launch_song_to_song(const float* seeds, uint32_t n_seeds, const float* cand
                          const float* M, uint32_t* order, unsigned long long* slots, uint32_t* sync, uint32_t grid,
                          hipStream_t st) {
     if (n == 0) return;
-    hipLaunchKernelGGL(song_to_song_kernel, dim3(grid), dim3(256), 0, st, seeds, n_seeds, cand, n, d, metric, M, order,
-                       slots, sync);
+    const uint32_t per = (n + grid * 256 - 1) / (grid * 256);
+#define S2S(DD, PP) hipLaunchKernelGGL((song_to_song_kernel<DD, PP>), dim3(grid), dim3(256), 0, st, seeds, n_seeds, cand, n, d, \
+                                       metric, M, order, slots, sync)
+    if (d == 23 && per <= 1) S2S(23, 1);
+    else if (d == 23 && per <= 2) S2S(23, 2);
+    else if (d == 23 && per <= 4) S2S(23, 4);
+    else if (d == 20 && per <= 1) S2S(20, 1);
+    else if (d == 20 && per <= 2) S2S(20, 2);
+    else if (d == 20 && per <= 4) S2S(20, 4);
+    else S2S(1, 0);
+#undef S2S
 }
 
 }  // namespace bg

@@ -59,6 +59,48 @@ int main(int argc, char** argv) {
     try { z.distance(Analysis(std::vector<float>(23, 0.f), FeaturesVersion::Version2)); CHECK(false); } catch (const std::logic_error&) {}
     try { Analysis(std::vector<float>(3, 0.f), LATEST); CHECK(false); } catch (const BlissError& e) { CHECK(e.kind == BlissError::Kind::ProviderError); }
     try { features_version_try_from(3); CHECK(false); } catch (const BlissError& e) { CHECK(e.message == "This features' version (3) does not exist"); }
+    // ---- playlist ordering: the reference's own cases (src/playlist.rs:506-1007), pointers stand in for &Song ----
+    {
+        auto mk = [](const char* path, std::vector<float> v, const char* title = nullptr, const char* artist = nullptr) {
+            Song s2;
+            s2.path = path;
+            s2.analysis = Analysis(std::move(v), LATEST);
+            if (title) s2.title = title;
+            if (artist) s2.artist = artist;
+            return s2;
+        };
+        auto vec16 = [](float head, float x16) { std::vector<float> v(23, 1.0f); for (int i = 0; i < 16; i++) v[i] = head; v[16] = x16; return v; };
+        Song first = mk("path-to-first", std::vector<float>(23, 1.0f)), dupe = mk("path-to-dupe", std::vector<float>(23, 1.0f));
+        Song second = mk("path-to-second", vec16(2.0f, 1.9f), "dupe-title", "dupe-artist");
+        Song third = mk("path-to-third", vec16(2.0f, 2.5f), "dupe-title", "dupe-artist");
+        Song fourth = mk("path-to-fourth", vec16(2.0f, 0.0f), "dupe-title", "no-dupe-artist");
+        Song fifth = mk("path-to-fourth", vec16(2.0f, 0.001f));
+        Song fifth_b = mk("path-to-fifth", vec16(2.0f, 0.0f));
+        using V = std::vector<const Song*>;
+        // test_song_to_song (:733-858)
+        CHECK((song_to_song(V{&first}, V{&first, &third, &dupe, &second, &fourth}, euclidean_builder()) == V{&first, &dupe, &second, &third, &fourth}));
+        CHECK((song_to_song(V{&first}, V{&first, &dupe, &third, &fourth, &second}, euclidean_builder()) == V{&first, &dupe, &second, &third, &fourth}));
+        // test_sort_closest_to_songs (:860-1007): equal distances keep the candidates' order
+        CHECK((closest_to_songs(V{&first}, V{&fifth_b, &fourth, &first, &dupe, &second, &third}, euclidean_builder()) == V{&first, &dupe, &second, &fifth_b, &fourth, &third}));
+        CHECK((closest_to_songs(V{&first}, V{&second, &first, &fourth, &dupe, &third, &fifth_b}, euclidean_builder()) == V{&first, &dupe, &second, &fourth, &fifth_b, &third}));
+        // test_dedup_playlist_custom_distance (:506-731)
+        const V pl{&first, &dupe, &second, &third, &fourth, &fifth};
+        CHECK((dedup_playlist_custom_distance(pl, std::nullopt, euclidean_builder()) == V{&first, &second, &fourth}));
+        CHECK((dedup_playlist_custom_distance(pl, 20.0f, euclidean_builder()) == V{&first}));
+        CHECK((dedup_playlist_custom_distance(pl, 20.0f, cosine_builder()) == V{&first}));
+        CHECK((dedup_playlist(pl, 20.0f) == V{&first}));
+        CHECK((dedup_playlist(pl, std::nullopt) == V{&first, &second, &fourth}));
+        // variance_based_weight_matrix (:1663-1765)
+        auto m = variance_based_weight_matrix({{1.0f, 0.0f, 1.0f}, {1.0f, 100.0f, 1.0f}, {1.0f, 200.0f, 1.0f}});
+        CHECK(m.size() == 9 && m[0] > m[4] && m[8] > m[4] && m[1] == 0.0f && m[3] == 0.0f);
+        CHECK(std::fabs(m[0] + m[4] + m[8] - 3.0f) < 1e-4f);
+        try { variance_based_weight_matrix({{1.0f, 2.0f, 3.0f}}); CHECK(false); } catch (const BlissError& e) { CHECK(e == ProviderError("seeds must contain more than one element")); }
+        try { variance_based_weight_matrix({{1.0f, 2.0f, 3.0f}, {1.0f, 2.0f}}); CHECK(false); } catch (const BlissError& e) { CHECK(e == ProviderError("all seed feature vectors must have the same length")); }
+        try { variance_based_weight_matrix({{}, {}}); CHECK(false); } catch (const BlissError& e) { CHECK(e == ProviderError("seed feature vectors must not be empty")); }
+        // the adaptive metric plugs into the Mahalanobis mode of the ordering functions
+        auto w = variance_based_weight_matrix({first.analysis.as_vec(), second.analysis.as_vec()});
+        CHECK((closest_to_songs(V{&first}, V{&third, &first}, mahalanobis_builder(w)) == V{&first, &third}));
+    }
     std::puts("test_bliss_audio: all checks passed");
     return 0;
 }
