@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--no-pairwise", action="store_true")
     ap.add_argument("--pairwise-n", type=int, default=100000)
     ap.add_argument("--cpu-songs", type=int, default=64)
+    ap.add_argument("--no-host-feed", action="store_true", help="skip the PCIe-inclusive host-buffer measurement")
+    ap.add_argument("--host-feed-songs", type=int, default=256)
     return ap.parse_args()
 
 
@@ -165,6 +167,39 @@ def main():
             result["cpu_baseline"] = cb
         elif not args.no_cpu_baseline:
             result["cpu_baseline"] = None
+
+        # ---- PCIe-inclusive rate of the host-buffer entry points (never `value`) ----
+        if not args.no_host_feed and world == 1 and N >= 8192:
+            import ctypes as C
+
+            from bliss_rs_amd import _ffi
+
+            hf = min(args.host_feed_songs, n)
+            L = _ffi.lib()
+            h_f32 = torch.empty(hf * N, dtype=torch.float32, pin_memory=True)
+            h_f32.copy_(pcm[: hf * N])
+            h_s16 = torch.empty(hf * N, dtype=torch.int16, pin_memory=True)
+            h_s16.copy_((pcm[: hf * N] * 32768.0).round().clamp(-32768, 32767).to(torch.int16))
+            pageable = h_f32.numpy().copy()
+            o64, l64 = offs[:hf].copy(), lens[:hf].copy()
+            res = np.empty((hf, d), np.float32)
+            st = np.empty(hf, np.int32)
+
+            def run(fn, ptr):
+                t0 = time.perf_counter()
+                _ffi.check(fn(ptr, o64.ctypes.data_as(C.POINTER(C.c_uint64)), l64.ctypes.data_as(C.POINTER(C.c_uint64)), hf, 2,
+                              res.ctypes.data, st.ctypes.data_as(C.POINTER(C.c_int32))))
+                return hf / (time.perf_counter() - t0)
+
+            run(L.blissgpu_analyze_batch, h_f32.data_ptr())  # warm-up (allocations)
+            feed = {"songs": hf,
+                    "f32_pinned_songs_per_sec": round(run(L.blissgpu_analyze_batch, h_f32.data_ptr()), 1),
+                    "f32_pageable_songs_per_sec": round(run(L.blissgpu_analyze_batch, pageable.ctypes.data), 1),
+                    "s16_pinned_songs_per_sec": round(run(L.blissgpu_analyze_batch_s16, h_s16.data_ptr()), 1)}
+            feed["f32_pinned_GBps"] = round(feed["f32_pinned_songs_per_sec"] * N * 4 / 1e9, 2)
+            feed["note"] = "blissgpu_analyze_batch[_s16] from host memory: H2D of one group pipelined with the analysis of the previous"
+            result["host_feed"] = feed
+            del h_f32, h_s16, pageable
 
         # ---- pairwise distances/sec over 100 k feature vectors (BASELINE configs[3]) ----
         if not args.no_pairwise and world == 1:

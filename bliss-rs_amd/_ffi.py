@@ -32,6 +32,10 @@ SIGNATURES = {
     "blissgpu_feature_count": (C.c_uint32, [C.c_uint32]),
     "blissgpu_analyze": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _i32p]),
     "blissgpu_analyze_batch": (C.c_int, [_vp, _u64p, _u64p, C.c_uint32, C.c_uint32, _vp, _i32p]),
+    "blissgpu_analyze_batch_s16": (C.c_int, [_vp, _u64p, _u64p, C.c_uint32, C.c_uint32, _vp, _i32p]),
+    "blissgpu_pcm_s16_to_f32_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "blissgpu_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
+    "blissgpu_host_free": (C.c_int, [_vp]),
     "blissgpu_analyze_batch_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, C.c_uint32, _vp, _vp]),
     "blissgpu_distance": (C.c_int, [_vp, _vp, C.c_uint32, C.c_int, _vp, _f32p]),
     "blissgpu_pairwise": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp]),

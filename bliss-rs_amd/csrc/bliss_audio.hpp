@@ -148,6 +148,28 @@ inline std::vector<BlissResult<Analysis>> analyze_batch(const std::vector<std::v
     return res;
 }
 
+// Same for decoders that deliver s16 mono 22 050 Hz PCM: 2 bytes per sample over PCIe, widened on the device exactly
+// like FFmpeg's s16 -> flt conversion (sample / 32768, src/song/decoder/ffmpeg.rs:36-109).
+inline std::vector<BlissResult<Analysis>> analyze_batch(const std::vector<std::vector<int16_t>>& songs, const AnalysisOptions& opt = {}) {
+    const uint32_t n = static_cast<uint32_t>(songs.size());
+    const size_t d = feature_count(opt.features_version);
+    std::vector<uint64_t> off(n), len(n);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) { off[i] = total; len[i] = songs[i].size(); total += len[i]; }
+    std::vector<int16_t> pcm(total ? total : 1);
+    for (uint32_t i = 0; i < n; i++) std::copy(songs[i].begin(), songs[i].end(), pcm.begin() + off[i]);
+    std::vector<float> out(n * d);
+    std::vector<int32_t> status(n);
+    if (n) check(blissgpu_analyze_batch_s16(pcm.data(), off.data(), len.data(), n, static_cast<uint32_t>(opt.features_version), out.data(), status.data()));
+    std::vector<BlissResult<Analysis>> res;
+    res.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (status[i] == BLISSGPU_SONG_OK) res.emplace_back(Analysis(std::vector<float>(out.begin() + i * d, out.begin() + (i + 1) * d), opt.features_version));
+        else res.emplace_back(AnalysisError("empty or too short song."));
+    }
+    return res;
+}
+
 // ---- Song (src/song/mod.rs:45-76, 373-522) ----
 struct Song {
     std::string path;

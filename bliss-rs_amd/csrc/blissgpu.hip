@@ -386,6 +386,106 @@ int is_diag(const float* M, uint32_t d) {
 
 }  // namespace
 
+// Host-buffer batches (the PCM feed): songs are packed group by group into one of TWO device PCM
+// buffers; the H2D copies of group g + 1 run on the copy stream while group g is analysed, so the transfer -- the
+// real bottleneck of this entry point (a 3-minute song is 15.9 MB, 7.9 MB as s16) -- is never idle.  BYTES = 4:
+// f32 samples copied verbatim; BYTES = 2: s16 samples, widened on the device by pcm_s16_to_f32 (sample / 32768,
+// exactly FFmpeg's s16 -> flt conversion, src/song/decoder/ffmpeg.rs:36-109).
+template <typename SampleT>
+static int analyze_batch_host(const SampleT* pcm, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
+                              uint32_t features_version, float* out, int32_t* status, const char* who) {
+    if (n_songs && (!pcm || !offsets || !lengths || !out)) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
+    const uint32_t d = blissgpu_feature_count(features_version);
+    if (!d) return fail(BLISSGPU_ERR_INVALID, who, "features_version must be 1 or 2");
+    if (n_songs == 0) return BLISSGPU_OK;
+    blissgpu_ctx* c;
+    int rc = default_ctx(&c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    constexpr bool S16 = sizeof(SampleT) == 2;
+    // groups of <= 2 GiB of f32 PCM (~128 three-minute songs): large enough to fill the GPU, small enough to pipeline
+    const uint64_t group_cap = 512ull << 20;  // samples
+    struct Group { uint32_t i0, n; std::vector<uint64_t> doff, dlen; uint64_t total; };
+    std::vector<Group> groups;
+    for (uint32_t i0 = 0; i0 < n_songs;) {
+        Group g{i0, 0, {}, {}, 0};
+        uint32_t i1 = i0;
+        while (i1 < n_songs && (i1 == i0 || g.total + lengths[i1] <= group_cap)) {
+            g.doff.push_back(g.total);
+            g.dlen.push_back(lengths[i1]);
+            g.total += (lengths[i1] + 63) / 64 * 64;
+            i1++;
+        }
+        g.n = i1 - i0;
+        groups.push_back(std::move(g));
+        i0 = i1;
+    }
+    uint64_t max_total = 64, max_n = 1;
+    for (const auto& g : groups) { max_total = std::max(max_total, g.total); max_n = std::max<uint64_t>(max_n, g.n); }
+    const int nbuf = groups.size() > 1 ? 2 : 1;
+    float* d_pcm[2] = {nullptr, nullptr};
+    SampleT* d_raw[2] = {nullptr, nullptr};  // s16 staging (S16 only)
+    float* d_out[2] = {nullptr, nullptr};
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+        for (int b = 0; b < 2; b++) {
+            (void)hipFree(d_pcm[b]); (void)hipFree(d_raw[b]); (void)hipFree(d_out[b]);
+            if (ev_copied[b]) (void)hipEventDestroy(ev_copied[b]);
+            if (ev_done[b]) (void)hipEventDestroy(ev_done[b]);
+        }
+    };
+    hipError_t e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+    for (int b = 0; b < nbuf && e == hipSuccess; b++) {
+        e = hipMalloc((void**)&d_pcm[b], max_total * sizeof(float));
+        if (e == hipSuccess && S16) e = hipMalloc((void**)&d_raw[b], max_total * sizeof(SampleT));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_out[b], max_n * d * sizeof(float));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_copied[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_done[b], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) { cleanup(); return fail(BLISSGPU_ERR_OOM, "hipMalloc(host batch)", hipGetErrorString(e)); }
+
+    auto upload = [&](size_t gi) -> hipError_t {  // H2D of group gi into buffer gi % nbuf, on the copy stream
+        const Group& g = groups[gi];
+        const int b = (int)(gi % nbuf);
+        hipError_t ee = hipSuccess;
+        if (gi >= (size_t)nbuf) ee = hipStreamWaitEvent(copy_stream, ev_done[b], 0);  // buffer b is free again
+        for (uint32_t k = 0; k < g.n && ee == hipSuccess; k++)
+            if (g.dlen[k]) {
+                void* dst = S16 ? (void*)(d_raw[b] + g.doff[k]) : (void*)(d_pcm[b] + g.doff[k]);
+                ee = hipMemcpyAsync(dst, pcm + offsets[g.i0 + k], g.dlen[k] * sizeof(SampleT), hipMemcpyHostToDevice, copy_stream);
+            }
+        if (ee == hipSuccess) ee = hipEventRecord(ev_copied[b], copy_stream);
+        return ee;
+    };
+
+    rc = BLISSGPU_OK;
+    e = upload(0);
+    for (size_t gi = 0; gi < groups.size() && e == hipSuccess && !rc; gi++) {
+        const Group& g = groups[gi];
+        const int b = (int)(gi % nbuf);
+        e = hipStreamWaitEvent(c->stream, ev_copied[b], 0);
+        if (e != hipSuccess) break;
+        if (S16) launch_pcm_s16_to_f32(reinterpret_cast<const int16_t*>(d_raw[b]), d_pcm[b], g.total, c->stream);
+        rc = blissgpu_analyze_batch_device(c, d_pcm[b], g.doff.data(), g.dlen.data(), g.n, features_version, d_out[b], nullptr);
+        if (rc) break;
+        e = hipMemcpyAsync(out + (size_t)g.i0 * d, d_out[b], (size_t)g.n * d * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(ev_done[b], c->stream);
+        // the next group's transfer overlaps this group's kernels (pageable sources block the host here, not the GPU)
+        if (e == hipSuccess && gi + 1 < groups.size()) e = upload(gi + 1);
+        if (status)
+            for (uint32_t k = 0; k < g.n; k++)
+                status[g.i0 + k] = g.dlen[k] >= (uint64_t)MIN_SAMPLES ? BLISSGPU_SONG_OK : BLISSGPU_SONG_TOO_SHORT;
+    }
+    if (e == hipSuccess && !rc) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(BLISSGPU_ERR_HIP, who, hipGetErrorString(e));
+    return BLISSGPU_OK;
+}
+
 extern "C" {
 
 const char* blissgpu_version(void) { return "blissgpu 0.1.0 (gfx950)"; }
@@ -516,57 +616,29 @@ int blissgpu_analyze_batch_device(blissgpu_ctx* c, const float* d_pcm, const uin
 
 int blissgpu_analyze_batch(const float* pcm, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
                            uint32_t features_version, float* out, int32_t* status) {
-    if (n_songs && (!pcm || !offsets || !lengths || !out))
-        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_batch", "NULL argument");
-    const uint32_t d = blissgpu_feature_count(features_version);
-    if (!d) return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_batch", "features_version must be 1 or 2");
-    if (n_songs == 0) return BLISSGPU_OK;
-    blissgpu_ctx* c;
-    int rc = default_ctx(&c);
-    if (rc) return rc;
+    return analyze_batch_host<float>(pcm, offsets, lengths, n_songs, features_version, out, status, "blissgpu_analyze_batch");
+}
+
+int blissgpu_analyze_batch_s16(const int16_t* pcm, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
+                               uint32_t features_version, float* out, int32_t* status) {
+    return analyze_batch_host<int16_t>(pcm, offsets, lengths, n_songs, features_version, out, status, "blissgpu_analyze_batch_s16");
+}
+
+int blissgpu_pcm_s16_to_f32_device(blissgpu_ctx* c, const int16_t* d_in, uint64_t n, float* d_out) {
+    if (!c || (n && (!d_in || !d_out))) return fail(BLISSGPU_ERR_INVALID, "blissgpu_pcm_s16_to_f32_device", "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
-    // pack the songs into device memory group by group (<= 8 GiB of PCM per group), 64-sample aligned
-    const uint64_t group_cap = 2ull << 30;  // samples
-    uint32_t i0 = 0;
-    while (i0 < n_songs) {
-        std::vector<uint64_t> doff, dlen;
-        uint64_t total = 0;
-        uint32_t i1 = i0;
-        while (i1 < n_songs && (i1 == i0 || total + lengths[i1] <= group_cap)) {
-            doff.push_back(total);
-            dlen.push_back(lengths[i1]);
-            total += (lengths[i1] + 63) / 64 * 64;
-            i1++;
-        }
-        const uint32_t ng = i1 - i0;
-        float *d_pcm = nullptr, *d_out = nullptr;
-        hipError_t e = hipMalloc((void**)&d_pcm, std::max<uint64_t>(total, 64) * sizeof(float));
-        if (e != hipSuccess) return fail(BLISSGPU_ERR_OOM, "hipMalloc(pcm)", hipGetErrorString(e));
-        e = hipMalloc((void**)&d_out, (size_t)ng * d * sizeof(float));
-        if (e != hipSuccess) { (void)hipFree(d_pcm); return fail(BLISSGPU_ERR_OOM, "hipMalloc(out)", hipGetErrorString(e)); }
-        for (uint32_t k = 0; k < ng; k++)
-            if (dlen[k]) {
-                e = hipMemcpyAsync(d_pcm + doff[k], pcm + offsets[i0 + k], dlen[k] * sizeof(float), hipMemcpyHostToDevice,
-                                   c->stream);
-                if (e != hipSuccess) { (void)hipFree(d_pcm); (void)hipFree(d_out); return fail(BLISSGPU_ERR_HIP, "hipMemcpyAsync", hipGetErrorString(e)); }
-            }
-        rc = blissgpu_analyze_batch_device(c, d_pcm, doff.data(), dlen.data(), ng, features_version, d_out, nullptr);
-        if (!rc) {
-            e = hipMemcpyAsync(out + (size_t)i0 * d, d_out, (size_t)ng * d * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) rc = fail(BLISSGPU_ERR_HIP, "copy back", hipGetErrorString(e));
-        }
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(d_pcm);
-        (void)hipFree(d_out);
-        if (rc) return rc;
-        if (status)
-            for (uint32_t k = 0; k < ng; k++)
-                status[i0 + k] = dlen[k] >= (uint64_t)MIN_SAMPLES ? BLISSGPU_SONG_OK : BLISSGPU_SONG_TOO_SHORT;
-        i0 = i1;
-    }
+    launch_pcm_s16_to_f32(d_in, d_out, n, c->stream);
+    HIP_TRY(hipGetLastError());
     return BLISSGPU_OK;
 }
+
+int blissgpu_host_alloc(void** p, uint64_t bytes) {
+    if (!p) return fail(BLISSGPU_ERR_INVALID, "blissgpu_host_alloc", "NULL");
+    hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? BLISSGPU_ERR_OOM : BLISSGPU_ERR_NO_DEVICE, "hipHostMalloc", hipGetErrorString(e));
+    return BLISSGPU_OK;
+}
+int blissgpu_host_free(void* p) { HIP_TRY(hipHostFree(p)); return BLISSGPU_OK; }
 
 int blissgpu_analyze(const float* pcm, uint64_t len, uint32_t features_version, float* out, int32_t* status) {
     const uint64_t off = 0;

@@ -158,6 +158,7 @@ void launch_summary(const Batch&, const Workspace&, hipStream_t);
 void launch_finalize(const Batch&, const Workspace&, uint32_t features_version, float* d_out, int32_t* dbg_tuning,
                      uint32_t* dbg_nbpms, hipStream_t);
 void launch_chroma_bank(double* bank, hipStream_t);
+void launch_pcm_s16_to_f32(const int16_t* in, float* out, uint64_t n, hipStream_t st);
 // playlist ordering (kernels_playlist.hip)
 void launch_set_distance(const float* seeds, uint32_t n_seeds, const float* cand, uint64_t n, uint32_t d, int metric,
                          const float* M, float* dist, uint32_t* keys, uint32_t* idx, uint32_t* nan_flag, hipStream_t st);

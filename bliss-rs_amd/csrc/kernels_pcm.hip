@@ -71,6 +71,30 @@ void launch_pcm_stats(const Batch& b, const Workspace& w, hipStream_t st) {
                        w.e256, w.zc256);
 }
 
+// ---- s16 -> f32 on the device: sample / 32768 (exact in f32), FFmpeg's AV_SAMPLE_FMT_S16 -> FLT conversion as used by
+// the reference's decoder (src/song/decoder/ffmpeg.rs:36-109); halves the PCIe bytes of the PCM feed ----
+__global__ __launch_bounds__(256) void pcm_s16_to_f32_kernel(const int16_t* __restrict__ in, float* __restrict__ out, uint64_t n) {
+    const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n && ((reinterpret_cast<uintptr_t>(in + i) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out + i) & 15) == 0)) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(in + i);  // 8 samples
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+        float4 lo, hi;
+        lo.x = (float)(int16_t)(w[0] & 0xFFFF) * (1.0f / 32768.0f); lo.y = (float)(int16_t)(w[0] >> 16) * (1.0f / 32768.0f);
+        lo.z = (float)(int16_t)(w[1] & 0xFFFF) * (1.0f / 32768.0f); lo.w = (float)(int16_t)(w[1] >> 16) * (1.0f / 32768.0f);
+        hi.x = (float)(int16_t)(w[2] & 0xFFFF) * (1.0f / 32768.0f); hi.y = (float)(int16_t)(w[2] >> 16) * (1.0f / 32768.0f);
+        hi.z = (float)(int16_t)(w[3] & 0xFFFF) * (1.0f / 32768.0f); hi.w = (float)(int16_t)(w[3] >> 16) * (1.0f / 32768.0f);
+        *reinterpret_cast<float4*>(out + i) = lo;
+        *reinterpret_cast<float4*>(out + i + 4) = hi;
+    } else {
+        for (uint64_t k = i; k < n && k < i + 8; k++) out[k] = (float)in[k] * (1.0f / 32768.0f);
+    }
+}
+
+void launch_pcm_s16_to_f32(const int16_t* in, float* out, uint64_t n, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(pcm_s16_to_f32_kernel, dim3((uint32_t)((n + 2047) / 2048)), dim3(256), 0, st, in, out, n);
+}
+
 // ---- synthetic white noise: uniform [-0.5, 0.5), Philox4x32-10, key = (0x5EED0000 + song, 0),
 // counter = (sample_index / 4, 0, 0, 0); bit-identical to oracle/bliss_oracle.c bo_white_noise ----
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t r[4]) {

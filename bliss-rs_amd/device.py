@@ -116,6 +116,18 @@ class Context:
                                                     d, _METRICS[metric], Mp, C.c_void_p(out.data_ptr()), out.stride(0)))
         return out
 
+    def pcm_s16_to_f32(self, pcm_s16, out=None):
+        """On-device s16 -> f32 (sample / 32768): FFmpeg's s16 -> flt conversion (src/song/decoder/ffmpeg.rs:36-109)."""
+        torch = self.torch
+        assert pcm_s16.is_cuda and pcm_s16.dtype == torch.int16
+        pcm_s16 = pcm_s16.contiguous()
+        if out is None:
+            out = torch.empty(pcm_s16.shape, dtype=torch.float32, device=pcm_s16.device)
+        _ffi.check(self._L.blissgpu_pcm_s16_to_f32_device(self._h, C.c_void_p(pcm_s16.data_ptr()), pcm_s16.numel(),
+                                                          C.c_void_p(out.data_ptr())))
+        self.synchronize()
+        return out
+
     # ---- playlist ordering on device-resident feature matrices (src/playlist.rs:24-59, 256-326) ----
     def _pl_args(self, seeds, cand, M):
         torch = self.torch

@@ -163,23 +163,28 @@ def analyze_batch(sample_arrays: Sequence[np.ndarray], options: Optional[Analysi
     (path, BlissResult<Song>) pairs of analyze_paths_with_options (src/song/decoder.rs:278-332)."""
     options = options or AnalysisOptions()
     version = FeaturesVersion(options.features_version)
-    arrays = [_as_pcm(a) for a in sample_arrays]
-    n = len(arrays)
+    sample_arrays = list(sample_arrays)
+    n = len(sample_arrays)
     if n == 0:
         return []
+    # int16 input (decoders that deliver s16 mono 22 050 Hz) crosses PCIe as 2 bytes per sample and is widened on the
+    # device exactly like FFmpeg's s16 -> flt conversion (sample / 32768); anything else is taken as f32 PCM
+    s16 = all(isinstance(a, np.ndarray) and a.dtype == np.int16 for a in sample_arrays)
+    arrays = [np.ascontiguousarray(a).reshape(-1) for a in sample_arrays] if s16 else [_as_pcm(a) for a in sample_arrays]
     lengths = np.array([len(a) for a in arrays], np.uint64)
     offsets = np.zeros(n, np.uint64)
     offsets[1:] = np.cumsum(lengths)[:-1]
     pcm = np.concatenate(arrays) if n > 1 else arrays[0]
     if pcm.size == 0:
-        pcm = np.zeros(1, np.float32)
+        pcm = np.zeros(1, np.int16 if s16 else np.float32)
     d = version.feature_count()
     out = np.empty((n, d), np.float32)
     status = np.empty(n, np.int32)
     L = _ffi.lib()
-    _ffi.check(L.blissgpu_analyze_batch(pcm.ctypes.data, offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                        lengths.ctypes.data_as(C.POINTER(C.c_uint64)), n, int(version),
-                                        out.ctypes.data, status.ctypes.data_as(C.POINTER(C.c_int32))))
+    fn = L.blissgpu_analyze_batch_s16 if s16 else L.blissgpu_analyze_batch
+    _ffi.check(fn(pcm.ctypes.data, offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                  lengths.ctypes.data_as(C.POINTER(C.c_uint64)), n, int(version),
+                  out.ctypes.data, status.ctypes.data_as(C.POINTER(C.c_int32))))
     results = []
     for i in range(n):
         if status[i] == _ffi.SONG_OK:

@@ -75,6 +75,16 @@ int blissgpu_analyze(const float *pcm, uint64_t len, uint32_t features_version, 
 int blissgpu_analyze_batch(const float *pcm, const uint64_t *offsets, const uint64_t *lengths, uint32_t n_songs,
                            uint32_t features_version, float *out, int32_t *status);
 
+/* Same, for decoders that deliver signed 16-bit mono 22 050 Hz PCM (what FFmpeg hands to the reference's resampler
+ * for the golden files, src/song/decoder/ffmpeg.rs:36-109): the samples cross PCIe as 2 bytes and are widened on the
+ * device with sample / 32768, FFmpeg's s16 -> flt conversion (bit-identical to converting on the host first).
+ * offsets / lengths are in samples.  Both host forms pipeline the transfer of one group of songs with the analysis
+ * of the previous one. */
+int blissgpu_analyze_batch_s16(const int16_t *pcm, const uint64_t *offsets, const uint64_t *lengths, uint32_t n_songs,
+                               uint32_t features_version, float *out, int32_t *status);
+/* The conversion alone, device to device (asynchronous on the context's stream). */
+int blissgpu_pcm_s16_to_f32_device(blissgpu_ctx *ctx, const int16_t *d_in, uint64_t n_samples, float *d_out);
+
 /* Device-resident form: d_pcm / d_out / d_status are HIP device pointers (d_status may be NULL),
  * offsets / lengths stay on the host (they size the launch).  Asynchronous on the context's
  * stream; call blissgpu_ctx_synchronize (or synchronise the stream) before reading d_out. */
@@ -132,6 +142,9 @@ int blissgpu_malloc(void **d_ptr, uint64_t bytes);
 int blissgpu_free(void *d_ptr);
 int blissgpu_memcpy_h2d(blissgpu_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int blissgpu_memcpy_d2h(blissgpu_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+/* Page-locked host memory for decoder output: H2D copies from it run at full PCIe rate without HIP's staging copy. */
+int blissgpu_host_alloc(void **h_ptr, uint64_t bytes);
+int blissgpu_host_free(void *h_ptr);
 
 /* ---- benchmark input: synthetic white noise written straight into HBM.  Song i of the call gets
  * uniform [-0.5, 0.5) samples from Philox4x32-10 with key (0x5EED0000 + first_song_index + i, 0) and

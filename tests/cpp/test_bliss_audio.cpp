@@ -3,6 +3,7 @@
 //   usage: test_bliss_audio <golden pcm s16 raw file> <expected 23 floats file>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 
@@ -41,6 +42,16 @@ int main(int argc, char** argv) {
     CHECK(std::fabs(song.analysis[AnalysisIndex::Zcr] - (-0.849141f)) < 1e-6f);
     AnalysisOptions v1{FeaturesVersion::Version1, 1};
     CHECK(dec.song_from_path_with_options(argv[1], v1).analysis.as_vec().size() == 20);
+    // s16 feed: widened on the device like FFmpeg's s16 -> flt conversion => bit-identical analysis
+    {
+        std::ifstream f(argv[1], std::ios::binary);
+        std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        std::vector<int16_t> s16(raw.size() / 2);
+        std::memcpy(s16.data(), raw.data(), s16.size() * 2);
+        auto r = analyze_batch(std::vector<std::vector<int16_t>>{s16, std::vector<int16_t>(10, 0)});
+        CHECK(std::get<Analysis>(r[0]) == song.analysis);
+        CHECK(std::get<BlissError>(r[1]) == AnalysisError("empty or too short song."));
+    }
     // bulk path: a missing file is reported, not fatal (src/song/decoder.rs:313-325)
     auto res = dec.analyze_paths({argv[1], "/nonexistent.raw"});
     CHECK(res.size() == 2);

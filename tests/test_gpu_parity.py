@@ -363,6 +363,60 @@ def test_decoder_trait_bulk_path(bliss, oracle, tmp_path, golden_pcm):
         v1.analysis[bliss.AnalysisIndex.Tempo]
 
 
+def test_pcm_feed_s16_and_pipelined_host_batches(bliss, ctx, oracle, golden_pcm):
+    """SURVEY.md 8 f1 (the pinnable part): s16 mono PCM is widened on the device exactly like FFmpeg's s16 -> flt
+    conversion -- the converted golden song has the reference's Adler-32 (src/song/decoder/ffmpeg.rs:455-462) -- and
+    the host entry points (f32 and s16, several pipelined groups, pinned or pageable source) agree bit for bit."""
+    import ctypes as C
+    import zlib
+
+    import torch
+
+    from bliss_rs_amd import _ffi
+
+    s16 = load_golden("s16_mono_22_5kHz.pcm_s16.npy").astype(np.int16)
+    dev = ctx.pcm_s16_to_f32(torch.from_numpy(s16).cuda()).cpu().numpy()
+    assert zlib.adler32(dev.astype("<f4").tobytes()) == 0x5E01930B
+    assert np.array_equal(dev, golden_pcm)
+    # odd offsets / tails exercise the scalar path of the conversion kernel
+    odd = ctx.pcm_s16_to_f32(torch.from_numpy(s16).cuda()[3:100003]).cpu().numpy()
+    assert np.array_equal(odd, golden_pcm[3:100003])
+
+    ref = bliss.analyze_batch([golden_pcm])[0].as_vec()
+    got = bliss.analyze_batch([s16])[0].as_vec()
+    assert np.array_equal(np.asarray(got), np.asarray(ref))
+
+    # > 512 Mi samples in one call => several groups, transfers overlapped with analysis; ragged, one too-short song
+    rng = np.random.default_rng(9)
+    n_long = 6
+    songs = [oracle.white_noise(100 + i, 100_000_000 if i < n_long else 50_000 + 1000 * i) for i in range(n_long + 4)]
+    songs.append(np.zeros(100, np.float32))
+    lens = np.array([len(x) for x in songs], np.uint64)
+    offs = np.zeros(len(songs), np.uint64)
+    offs[1:] = np.cumsum(lens)[:-1]
+    total = int(lens.sum())
+    L = _ffi.lib()
+    hp = C.c_void_p()
+    _ffi.check(L.blissgpu_host_alloc(C.byref(hp), total * 4))
+    try:
+        pinned = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_float)), shape=(total,))
+        for x, o in zip(songs, offs):
+            pinned[int(o):int(o) + len(x)] = x
+        out = np.empty((len(songs), 23), np.float32)
+        st = np.empty(len(songs), np.int32)
+        _ffi.check(L.blissgpu_analyze_batch(hp, offs.ctypes.data_as(C.POINTER(C.c_uint64)), lens.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            len(songs), 2, out.ctypes.data, st.ctypes.data_as(C.POINTER(C.c_int32))))
+    finally:
+        _ffi.check(L.blissgpu_host_free(hp))
+    assert st.tolist() == [0] * (len(songs) - 1) + [1]
+    # the same songs one group at a time (device-resident path) give the same rows
+    small, _ = _run(ctx, songs[n_long:n_long + 4])
+    assert np.array_equal(out[n_long:n_long + 4], small)
+    big, _ = _run(ctx, songs[:1])
+    assert np.array_equal(out[0], big[0])
+    assert np.isnan(out[-1]).all()
+
+
 def test_cpp_host_mirror(tmp_path, literals):
     """bliss-rs_amd/csrc/bliss_audio.hpp (the compiled host layer above the C ABI) on the GPU."""
     import subprocess
