@@ -149,7 +149,7 @@ __device__ __forceinline__ float ref_floor_f32(double ref) {
 
 // The f64 interpolation above is only needed bit-exactly near a decision boundary.  For an established peak
 // (sa <= se, sb < se) the f32 evaluation below is within 2 ulp(se) of the f64 magnitude: |avg| <= den / 2
-// bounds the interpolation term by se / 8 and its error by ~0.5 ulp(se), den > 0 is never rounded to zero
+// bounds the interpolation term by se / 4 and its error by ~0.5 ulp(se), den > 0 is never rounded to zero
 // (2 se - sa >= se > sb), plus two final roundings.  A 16-ulp guard band around the coarse-bin edges
 // (2^18 ulp apart) therefore makes the f32 bin provably equal to coarse_bin() of the f64 magnitude;
 // the ~1e-4 of peaks inside the band take the f64 path.
@@ -533,7 +533,25 @@ void launch_tune_select(const Batch& b, const Workspace& w, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 constexpr int P2_SLOW_CAP = 1024;  // per-wave list of peaks that need the f64 path
 constexpr int P2_FRAMES_PER_WAVE = CH_TILE / 4;
+constexpr int P2_FAST_CAP = 768;   // per-wave list of one frame's peaks at or above the median's coarse bins (<= 714)
+constexpr int P2_C0 = 56;          // first bin held in registers (multiple of 4, = PIP_LO - 1)
+constexpr int P2_CHUNKS = 6;       // float4 chunks per lane: bins 56 .. 56 + 4*64*6 - 1 = 1591 >= PIP_HI + 1
 
+// whole-wave rotations by one lane (GFX9 DPP wave_ror:1 / wave_rol:1)
+__device__ __forceinline__ float wave_ror1(float v) {  // lane l <- lane l - 1, lane 0 <- lane 63
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_rol1(float v) {  // lane l <- lane l + 1, lane 63 <- lane 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134, 0xF, 0xF, false));
+}
+
+// A wave owns a frame at a time: the 1536 magnitudes that can hold peaks are loaded as six 16-byte loads per lane
+// (the next frame's are in flight meanwhile), neighbours come from lane rotations, and a peak is classified with
+// two thresholds before any arithmetic: the interpolated magnitude lies in [se, 1.25 se], so se < 0.8 E(b_lo) is
+// certainly below the median's coarse bins (dropped: half of all peaks) and se >= E(b_hi + 1) certainly above.
+// Peaks at or above the median's bins are compacted into an LDS list so the pitch-bin arithmetic runs on dense
+// wavefronts; the few that need f64 (guard-band hits, candidates inside the median's bins) go to a second list
+// that is flushed across frames.
 __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                          const uint32_t* __restrict__ pfx_ct,
                                                          const float* __restrict__ spec,
@@ -545,6 +563,7 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
     __shared__ uint32_t hist[N_TUNING];
     __shared__ uint32_t slow_list[4][P2_SLOW_CAP];  // (frame slot << 16) | centre bin
     __shared__ uint32_t slow_count[4];
+    __shared__ uint16_t fast_list[4][P2_FAST_CAP];  // (kind << 12) | centre bin; kind 1 = above, 2 = inside
     const uint32_t s = find_segment(pfx_ct, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
     const uint32_t tile = blockIdx.x - pfx_ct[s];
@@ -555,9 +574,10 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
     if (tid < N_TUNING) hist[tid] = 0;
     if (lane == 0) slow_count[wave] = 0;
     __syncthreads();
-    // wave w owns frames tile*CH_TILE + w + 4 i.  Most peaks are classified in f32 (see peak_coarse_bin /
-    // peak_pitch_bin_f32); the rest -- candidates inside the median's coarse bins and peaks whose f32 pitch
-    // bin is not provable -- are queued and run through the f64 path on densely packed wavefronts.
+    // E(b) = smallest float of coarse bin b
+    const float t_lo = __uint_as_float(b_lo << 18) * 0.79999f;
+    const float t_hi = (b_hi + 1 < (uint32_t)H1_BINS) ? __uint_as_float((b_hi + 1) << 18) : __builtin_inff();
+
     auto flush = [&]() {
         const uint32_t n_slow = slow_count[wave];
         for (uint32_t i = lane; i < n_slow; i += WAVE) {
@@ -582,39 +602,88 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
         if (lane == 0) slow_count[wave] = 0;
         __builtin_amdgcn_wave_barrier();
     };
+    auto wave_push = [&](bool want, uint32_t value, auto store, uint32_t& count) {  // count is wave-uniform
+        const uint64_t mask = __ballot(want);
+        if (mask) {
+            if (want) store(count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), value);
+            count += (uint32_t)__popcll(mask);
+        }
+    };
+    auto load_row = [&](uint32_t f, float4 (&q)[P2_CHUNKS], float& edge) {
+        const float* row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
+#pragma unroll
+        for (int k = 0; k < P2_CHUNKS; k++) q[k] = *reinterpret_cast<const float4*>(row + P2_C0 + 4 * (lane + 64 * k));
+        edge = row[P2_C0 - 1];
+    };
+
+    float4 q[P2_CHUNKS], qn[P2_CHUNKS];
+    float edge = 0.0f, edge_n = 0.0f;
+    const uint32_t f_first = tile * CH_TILE + wave;
+    if (f_first < sd.n_c) load_row(f_first, qn, edge_n);
     for (int i = 0; i < P2_FRAMES_PER_WAVE; i++) {
         const uint32_t f = tile * CH_TILE + wave + 4 * i;
-        if (f >= sd.n_c) break;
+        if (f >= sd.n_c) break;  // wave-uniform
+#pragma unroll
+        for (int k = 0; k < P2_CHUNKS; k++) q[k] = qn[k];
+        edge = edge_n;
+        if (i + 1 < P2_FRAMES_PER_WAVE && f + 4 < sd.n_c) load_row(f + 4, qn, edge_n);
         const float* row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
         const double ref = 0.1 * (double)frame_max[sd.c_off + f];
-        const float thr = ref_floor_f32(ref);
+        const float thr0 = ref_floor_f32(ref);
+        const float thr = thr0 > t_lo ? thr0 : t_lo;  // se must exceed ref AND reach the median's neighbourhood
+        const bool strict_lo = t_lo > thr0;           // then thr = t_lo, an INCLUSIVE bound (se >= t_lo implies se > thr0)
         if (slow_count[wave] + PIP_MAX_PER_FRAME > P2_SLOW_CAP) flush();  // wave-uniform
-        float sb = row[PIP_LO - 1 + lane], se = row[PIP_LO + lane];
-        for (int c = PIP_LO + lane; c < PIP_LO + 23 * WAVE; c += WAVE) {  // uniform trip count (ballots inside)
-            const bool in = c <= PIP_HI;
-            const float sa = in ? row[c + 1] : 0.0f;
+        uint32_t n_fast = 0;
+#pragma unroll
+        for (int k = 0; k < P2_CHUNKS; k++) {
+            const float rw = wave_ror1(q[k].w);
+            const float rw_prev = (k > 0) ? wave_ror1(q[k > 0 ? k - 1 : 0].w) : edge;
+            const float left = (lane == 0) ? rw_prev : rw;
+            const float sx = wave_rol1(q[k].x);
+            const float sx_next = (k + 1 < P2_CHUNKS) ? wave_rol1(q[k + 1 < P2_CHUNKS ? k + 1 : k].x) : 0.0f;
+            const float right = (lane == 63) ? sx_next : sx;
+            const float m[6] = {left, q[k].x, q[k].y, q[k].z, q[k].w, right};
+            const int c0 = P2_C0 + 4 * (lane + 64 * k);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int c = c0 + e;
+                const float sb = m[e], se = m[e + 1], sa = m[e + 2];
+                uint32_t kind = 0;
+                if (c >= PIP_LO && c <= PIP_HI && sa <= se && sb < se && (strict_lo ? se >= thr : se > thr)) {
+                    if (se >= t_hi) {
+                        kind = 1;
+                    } else {
+                        const uint32_t b = peak_coarse_bin(sb, se, sa, ref, c);
+                        kind = b > b_hi ? 1u : (b >= b_lo ? 2u : 0u);
+                    }
+                }
+                wave_push(kind != 0, (kind << 12) | (uint32_t)c,
+                          [&](uint32_t pos, uint32_t v) { fast_list[wave][pos] = (uint16_t)v; }, n_fast);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // dense pass: pitch bins in f32 where provable; everything else is queued for the f64 path
+        uint32_t n_slow = slow_count[wave];
+        for (uint32_t j = lane; j < ((n_fast + WAVE - 1) / WAVE) * WAVE; j += WAVE) {  // uniform trip count
             bool slow = false;
-            if (in && sa <= se && sb < se && se > thr) {
-                const uint32_t b = peak_coarse_bin(sb, se, sa, ref, c);
-                if (b > b_hi) {
-                    const int pb = peak_pitch_bin_f32(sb, se, sa, c);
+            int c = 0;
+            if (j < n_fast) {
+                const uint32_t e = fast_list[wave][j];
+                c = (int)(e & 0xFFFu);
+                if ((e >> 12) == 1u) {
+                    const int pb = peak_pitch_bin_f32(row[c - 1], row[c], row[c + 1], c);
                     if (pb >= 0) atomicAdd(&hist[pb], 1u);
                     else slow = true;
-                } else if (b >= b_lo) {
+                } else {
                     slow = true;
                 }
             }
-            const uint64_t mask = __ballot(slow);
-            if (mask) {
-                uint32_t base = 0;
-                if (lane == 0) { base = slow_count[wave]; slow_count[wave] = base + (uint32_t)__popcll(mask); }
-                base = __shfl(base, 0, WAVE);
-                if (slow) slow_list[wave][base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = ((uint32_t)i << 16) | (uint32_t)c;
-            }
-            // next stride: the three magnitudes are re-read (they are 63 bins further on)
-            sb = row[c + WAVE - 1];
-            se = row[c + WAVE];
+            wave_push(slow, ((uint32_t)i << 16) | (uint32_t)c,
+                      [&](uint32_t pos, uint32_t v) { slow_list[wave][pos] = v; }, n_slow);
         }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) slow_count[wave] = n_slow;
+        __builtin_amdgcn_wave_barrier();
     }
     flush();
     __syncthreads();
