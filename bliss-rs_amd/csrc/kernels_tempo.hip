@@ -136,7 +136,8 @@ __device__ float bt_timesig(const float* acf, long gp) {
 }
 
 struct BtShared {
-    float dfframe[BT_WINLEN], dfrev[BT_WINLEN], acf[BT_WINLEN], phout[BT_WINLEN], dfwv[BT_WINLEN];
+    float dfframe[2 * BT_WINLEN];  // [512, 1024) stays zero: the ACF loops below read past the frame instead of predicating
+    float dfrev[BT_WINLEN], acf[BT_WINLEN], phout[BT_WINLEN], dfwv[BT_WINLEN];
     float acfout[BT_LAGLEN], rwv[BT_LAGLEN], gwv[BT_LAGLEN], out[BT_STEP];
     float phwv[2 * BT_LAGLEN];
     float red_val[4];
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void beat_kernel(const SongDesc* __restrict__ 
     float* rbpm = run_bpm + (size_t)s * runs_pitch;
     uint32_t* rcnt = run_cnt + (size_t)s * runs_pitch;
 
-    for (int i = tid; i < BT_WINLEN; i += 256) sh.dfwv[i] = dfwv_tab[i];
+    for (int i = tid; i < BT_WINLEN; i += 256) { sh.dfwv[i] = dfwv_tab[i]; sh.dfframe[BT_WINLEN + i] = 0.0f; }
     for (int i = tid; i < BT_LAGLEN; i += 256) { sh.rwv[i] = rwv_tab[i]; sh.gwv[i] = 0.0f; }
     for (int i = tid; i < 2 * BT_LAGLEN; i += 256) sh.phwv[i] = 1.0f;
     if (tid == 0) {
@@ -192,8 +193,42 @@ __global__ __launch_bounds__(256) void beat_kernel(const SongDesc* __restrict__ 
         __syncthreads();
         // dfrev = reverse(dfframe * dfwv)
         for (int i = tid; i < BT_WINLEN; i += 256) sh.dfrev[BT_WINLEN - 1 - i] = sh.dfframe[i] * sh.dfwv[i];
-        // vec_autocorr (:819-828): thread t computes lags t and 511-t (513 MACs in total)
-        {
+        // vec_autocorr (:819-828): acf[L] = (sum_{j=L}^{511} f[j-L] f[j]) / (512 - L), summed in j order.  Thread t computes
+        // lags t and 511-t (513 products in total).  Written over i = j - L the first factor f[i] is the same for every
+        // lane, so for runs whose frame lies inside the song it comes from SCALAR loads of the thresholded series and
+        // only f[i + L] is an LDS read; the loops run to the wave-uniform bound and read the zero padding behind the
+        // frame instead of predicating (x + f[i] * 0 == x exactly, so the sums are bit-identical).
+        if (m >= 4) {
+            const float* __restrict__ fs = thr + (128 * (m + 1) - 512) - 1;  // fs[i] == dfframe[i], wave-uniform
+            const int wave = tid >> 6;
+            {
+                const float* va = sh.dfframe + tid;  // va[i] = f[i + lag], lag = tid
+                float acc = 0.0f;
+                const int na = BT_WINLEN - 64 * wave;
+                for (int i = 0; i < na; i += 16) {
+                    float sv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) sv[u] = fs[i + u];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) acc += sv[u] * va[i + u];
+                }
+                sh.acf[tid] = acc / (float)(BT_WINLEN - tid);
+            }
+            {
+                const int lag = BT_WINLEN - 1 - tid;
+                const float* vb = sh.dfframe + lag;
+                float acc = 0.0f;
+                const int nb = 64 * wave + 64;
+                for (int i = 0; i < nb; i += 16) {
+                    float sv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) sv[u] = fs[i + u];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) acc += sv[u] * vb[i + u];
+                }
+                sh.acf[lag] = acc / (float)(BT_WINLEN - lag);
+            }
+        } else {
             const int lag_a = tid, lag_b = BT_WINLEN - 1 - tid;
             float acc = 0.0f;
             for (int j = lag_a; j < BT_WINLEN; j++) acc += sh.dfframe[j - lag_a] * sh.dfframe[j];
