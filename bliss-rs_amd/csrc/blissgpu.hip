@@ -348,15 +348,25 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
     // The beat tracker (one 256-thread workgroup per song) would displace one of the three FFT-8192 workgroups
     // per CU (168 VGPRs each), so it starts only after that kernel and runs beside the HBM-bound tuning / chroma
     // kernels, which leave registers free.  BLISSGPU_OVERLAP=1 (experiment): start it beside the FFT-8192 kernel.
-    if (two && c->overlap_mode != 1) {
+    if (two && c->overlap_mode == 0) {
         HIP_TRY(hipEventRecord(c->ev_stft, st));
         HIP_TRY(hipStreamWaitEvent(sb, c->ev_stft, 0));
     }
-    { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
-    if (two) HIP_TRY(hipEventRecord(c->ev_join, sb));
+    if (c->overlap_mode != 3) {
+        { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
+        if (two) HIP_TRY(hipEventRecord(c->ev_join, sb));
+    }
     { Prof p(c, K_TUNE_SELECT); launch_tune_select(b, w, st); }
     { Prof p(c, K_TUNE_PASS2); launch_tune_pass2(b, w, st); }
     { Prof p(c, K_TUNE_FINAL); launch_tune_final(b, w, st); }
+    if (c->overlap_mode == 3) {  // experiment: beat tracker beside the chroma contraction only
+        if (two) {
+            HIP_TRY(hipEventRecord(c->ev_stft, st));
+            HIP_TRY(hipStreamWaitEvent(sb, c->ev_stft, 0));
+        }
+        { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
+        if (two) HIP_TRY(hipEventRecord(c->ev_join, sb));
+    }
     { Prof p(c, K_CHROMA); launch_chroma(b, w, c->tables, st); }
     if (two) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
     { Prof p(c, K_FINALIZE); launch_finalize(b, w, features_version, d_out, c->dbg_tuning.p, c->dbg_nbpms.p, st); }

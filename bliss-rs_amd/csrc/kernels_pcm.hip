@@ -21,6 +21,39 @@ __global__ __launch_bounds__(256) void pcm_stats_kernel(const float* __restrict_
     const float* __restrict__ x = pcm + sd.pcm_off;
     const int lane = lane_id(), wave = wave_id();
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    {
+        // fast path: the wave's four blocks are complete and 16-byte aligned -> all four loads in flight at once
+        const uint32_t q0 = tile * PCM_TILE_BLOCKS + wave * (PCM_TILE_BLOCKS / 4);
+        if (aligned16 && (uint64_t)(q0 + PCM_TILE_BLOCKS / 4) * 256 <= sd.n) {  // wave-uniform
+            const uint64_t base0 = (uint64_t)q0 * 256;
+            float4 v[PCM_TILE_BLOCKS / 4];
+#pragma unroll
+            for (int i = 0; i < PCM_TILE_BLOCKS / 4; i++) v[i] = *reinterpret_cast<const float4*>(x + base0 + 256 * i + 4 * lane);
+            uint32_t carry = (x[base0 > 0 ? base0 - 1 : 0] > 0.0f) ? 1u : 0u;  // positivity of the sample before the block
+            float ss[PCM_TILE_BLOCKS / 4];
+            uint32_t zc[PCM_TILE_BLOCKS / 4];
+#pragma unroll
+            for (int i = 0; i < PCM_TILE_BLOCKS / 4; i++) {
+                const float4 w = v[i];
+                ss[i] = (w.x * w.x + w.y * w.y) + (w.z * w.z + w.w * w.w);
+                const uint32_t p0 = w.x > 0.0f, p1 = w.y > 0.0f, p2 = w.z > 0.0f, p3 = w.w > 0.0f;
+                uint32_t before = __shfl_up(p3, 1, WAVE);
+                if (lane == 0) before = carry;
+                zc[i] = (p0 != before) + (p1 != p0) + (p2 != p1) + (p3 != p2);
+                carry = __shfl(p3, 63, WAVE);
+            }
+#pragma unroll
+            for (int i = 0; i < PCM_TILE_BLOCKS / 4; i++) {
+                const float s_tot = wave_sum(ss[i]);
+                const uint32_t z_tot = wave_sum(zc[i]);
+                if (lane == 0) {
+                    e256[sd.e_off + q0 + i] = s_tot;
+                    zc256[sd.e_off + q0 + i] = z_tot;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < PCM_TILE_BLOCKS / 4; i++) {
         const uint32_t q = tile * PCM_TILE_BLOCKS + wave * (PCM_TILE_BLOCKS / 4) + i;
