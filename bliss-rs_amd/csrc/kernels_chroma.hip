@@ -209,6 +209,7 @@ __device__ constexpr float CONST_SIN32[8] = {0.0f, 0.19509032201612827f, 0.38268
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+// (non-temporal LOADS of the spectrogram were tried in pass 2 and the chroma contraction: 8-12 % slower)
 // 8-byte load through a buffer descriptor: 32-bit lane offset + scalar offset (no 64-bit address VGPRs)
 __device__ __forceinline__ f2 buf_load_f2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
@@ -396,12 +397,15 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
         // loads at the end of the iteration is "all but the stores" and never waits for an HBM write acknowledge.
         if (ABL != 7) {
             const __amdgpu_buffer_rsrc_t r_row = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(spec + (sd.c_off + f) * (size_t)CBINS_PAD), 0, CBINS_PAD * 4, 0x00020000);
+                (void*)(spec + (sd.c_off + (ABL == 16 ? (f & 15) : f)) * (size_t)CBINS_PAD), 0, CBINS_PAD * 4, 0x00020000);
             const u32x4_t* mags4 = reinterpret_cast<const u32x4_t*>(lds);
 #pragma unroll
             for (int i = 0; i < 5; i++) {
                 const int q = t + 256 * i;
-                if (i < 4 || q < CBINS_PAD / 4) __builtin_amdgcn_raw_buffer_store_b128(mags4[q], r_row, 16u * (uint32_t)q, 0, 0);
+                if (i < 4 || q < CBINS_PAD / 4) {
+                    if (ABL == 17) __builtin_amdgcn_raw_buffer_store_b128(mags4[q], r_row, 16u * (uint32_t)q, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(mags4[q], r_row, 16u * (uint32_t)q, 0, 2);  // nt: streamed once
+                }
             }
         }
         mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -468,6 +472,8 @@ void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, 
     else if (abl == 13) LAUNCH_STFT(13);
     else if (abl == 14) LAUNCH_STFT(14);
     else if (abl == 15) LAUNCH_STFT(15);
+    else if (abl == 16) LAUNCH_STFT(16);
+    else if (abl == 17) LAUNCH_STFT(17);
     else if (occ == 4)
         hipLaunchKernelGGL((stft8192_kernel<0, 4>), dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs,
                            b.pfx_c, t.hann8192, t.tw8192, t.tw_p1, w.spec, w.frame_max, w.h1);
@@ -868,7 +874,8 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
         for (int u = 0; u < NS; u++) {
             a[u] = *reinterpret_cast<const double4_t*>(arow + 16 * (st0 + u));
 #pragma unroll
-            for (int q = 0; q < 4; q++) b[u][q] = *reinterpret_cast<const float4*>(brow[q] + 16 * (st0 + u));
+            for (int q = 0; q < 4; q++)
+                b[u][q] = *reinterpret_cast<const float4*>(brow[q] + 16 * (st0 + u));
         }
 #pragma unroll
         for (int u = 0; u < NS; u++) {
