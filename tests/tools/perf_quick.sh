@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick perf+parity iteration on the GPU box: 256 songs, kernel table
-python bench.py --songs ${SONGS:-256} --steps 2 --warmup 1 --cpu-songs 8 --no-pairwise > gpurun_out/perf.log 2>&1; echo rc=$?
+python bench.py --songs ${SONGS:-256} --steps 2 --warmup 1 --cpu-songs 8 --no-pairwise --no-host-feed > gpurun_out/perf.log 2>&1; echo rc=$?
 tail -1 gpurun_out/perf.log | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
