@@ -141,9 +141,12 @@ int build_tables(blissgpu_ctx* c) {
         }
     // periodic Hann, evaluated in f32 exactly as src/utils.rs:37-39
     std::vector<float> hann(8192), hannz(512), rwv(BT_LAGLEN), dfwv(BT_WINLEN);
-    for (int n = 0; n < 8192; n++) hann[n] = 0.5f - 0.5f * cosf(2.0f * (float)n * PI_F / 8192.0f);
+    // Both device tables hold HALF the window: the real-input split needs X = (A + P) / 2, and a power-of-two scale
+    // commutes with every rounding of the (linear) transform, so halving the window once removes a multiply per bin
+    // and leaves every magnitude bit-identical.
+    for (int n = 0; n < 8192; n++) hann[n] = 0.5f * (0.5f - 0.5f * cosf(2.0f * (float)n * PI_F / 8192.0f));
     // hanningz, src/aubio.rs:151-154
-    for (int i = 0; i < 512; i++) hannz[i] = 0.5f * (1.0f - cosf(2.0f * PI_F * (float)i / 512.0f));
+    for (int i = 0; i < 512; i++) hannz[i] = 0.5f * (0.5f * (1.0f - cosf(2.0f * PI_F * (float)i / 512.0f)));
     // BeatTracking::new, src/aubio.rs:911-936
     const float rayparam = 60.0f * (float)SAMPLE_RATE / 120.0f / (float)HOP_B;
     const float dfwvnorm = expf((logf(2.0f) / rayparam) * (float)(BT_WINLEN + 2));

@@ -127,5 +127,8 @@ __device__ __forceinline__ float split_one_sq(f2 zk, f2 zm, f2 w) {
 
 // magnitude from 4 x |X|^2 with v_sqrt_f32 (<= 1 ulp; scaling by powers of two stays exact)
 __device__ __forceinline__ float mag_from_sq4(float sq4) { return 0.5f * __builtin_amdgcn_sqrtf(sq4); }
+// the kernels feed the transform with HALF the window (see the table construction in blissgpu.hip): Z arrives halved,
+// A + P is X itself and the magnitude needs no further scaling
+__device__ __forceinline__ float mag_from_sq(float sq) { return __builtin_amdgcn_sqrtf(sq); }
 
 }  // namespace bg

@@ -370,12 +370,12 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
                 const f2 zm = lds[k == 0 ? 2048 : 4096 - k];
                 split_pair_sq(v[R16(j)], (j == 0 && t == 0) ? v[R16(0)] : zm, w, sq_k, sq_m);
             }
-            m_lo[j] = mag_from_sq4(sq_k);
-            m_hi[j] = mag_from_sq4(sq_m);
+            m_lo[j] = mag_from_sq(sq_k);
+            m_hi[j] = mag_from_sq(sq_m);
             mx = fmaxf(mx, fmaxf(m_lo[j], m_hi[j]));
         }
         if (t == 0) {
-            m_mid = mag_from_sq4(split_one_sq(v[R16(8)], v[R16(8)], mk(0.0f, -1.0f)));  // k = 2048: W_8192^2048 = -i
+            m_mid = mag_from_sq(split_one_sq(v[R16(8)], v[R16(8)], mk(0.0f, -1.0f)));  // k = 2048: W_8192^2048 = -i
             mx = fmaxf(mx, m_mid);
         }
         const bool has_next = fi + 1 < STFT_FRAMES_PER_WG && f + 1 < sd.n_c;  // uniform

@@ -121,12 +121,13 @@ __device__ __forceinline__ void fft512_frame(__amdgpu_buffer_rsrc_t r_x, long re
         const f2 zm = tile[mi];
         if (ABL == 2) out.m[e] = zk.x + zm.y;
         else if (ABL == 5) out.m[e] = 0.5f * split_one_sq(zk, zm, tabs->tw512[16 * e + l]);
-        else if (ABL == 6) out.m[e] = mag_from_sq4(split_one_sq(zk, zm, mk(0.6f, 0.8f)));
-        else if (ABL == 7) out.m[e] = mag_from_sq4(split_one_sq(zk, zk, tabs->tw512[16 * e + l]));
-        else out.m[e] = mag_from_sq4(split_one_sq(zk, zm, tabs->tw512[16 * e + l]));  // W_512^k, k = 16 l + e
+        else if (ABL == 6) out.m[e] = mag_from_sq(split_one_sq(zk, zm, mk(0.6f, 0.8f)));
+        else if (ABL == 7) out.m[e] = mag_from_sq(split_one_sq(zk, zk, tabs->tw512[16 * e + l]));
+        else out.m[e] = mag_from_sq(split_one_sq(zk, zm, tabs->tw512[16 * e + l]));  // W_512^k, k = 16 l + e
     }
-    if (l == 0) out.m[0] = fabsf(z0.x + z0.y);
-    out.nyq = fabsf(z0.x - z0.y);
+    // Z is halved (half window): X[0] = 2 (Re Z[0] + Im Z[0]), X[256] = 2 (Re Z[0] - Im Z[0])
+    if (l == 0) out.m[0] = 2.0f * fabsf(z0.x + z0.y);
+    out.nyq = 2.0f * fabsf(z0.x - z0.y);
     __builtin_amdgcn_wave_barrier();
 }
 
