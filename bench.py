@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--pairwise-n", type=int, default=100000)
     ap.add_argument("--cpu-songs", type=int, default=64)
     ap.add_argument("--no-host-feed", action="store_true", help="skip the PCIe-inclusive host-buffer measurement")
+    ap.add_argument("--no-playlist", action="store_true", help="skip the playlist-ordering measurement")
     ap.add_argument("--host-feed-songs", type=int, default=256)
     return ap.parse_args()
 
@@ -226,6 +227,41 @@ def main():
                                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                "frac": round(pbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
             del D
+        # ---- playlist ordering over the same 100 k-vector library: closest_to_songs + song_to_song ----
+        if not args.no_playlist and not args.no_pairwise and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as O
+
+            m = args.pairwise_n
+            seeds = A[:3].clone()
+            ctx.closest_to_songs(seeds, A, "euclidean")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            order = ctx.closest_to_songs(seeds, A, "euclidean")
+            torch.cuda.synchronize()
+            t_sort = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            chain = ctx.song_to_song(seeds[:1], A, "euclidean")
+            torch.cuda.synchronize()
+            t_chain = time.perf_counter() - t0
+            A_h = A.cpu().numpy()
+            t0 = time.perf_counter()
+            ref_order, _ = O.closest_to_songs(seeds.cpu().numpy(), A_h, "euclidean")
+            t_sort_cpu = time.perf_counter() - t0
+            sub = 4000  # the CPU chain is O(n^2): time a 4000-song pool and scale by (m / sub)^2
+            t0 = time.perf_counter()
+            ref_chain = O.song_to_song(A_h[:1], A_h[:sub], "euclidean")
+            t_chain_cpu = time.perf_counter() - t0
+            result["playlist"] = {
+                "n": m, "d": d,
+                "closest_to_songs_ms": round(t_sort * 1e3, 3), "closest_to_songs_matches_oracle": bool(np.array_equal(order.cpu().numpy(), ref_order)),
+                "closest_to_songs_cpu_ms": round(t_sort_cpu * 1e3, 1),
+                "song_to_song_s": round(t_chain, 3), "song_to_song_steps_per_sec": round(m / t_chain, 1),
+                "song_to_song_cpu_s_extrapolated": round(t_chain_cpu * (m / sub) ** 2, 1),
+                "song_to_song_cpu_sample": f"oracle on a {sub}-song pool ({t_chain_cpu:.2f} s, 1 core), scaled by (n / {sub})^2",
+                "song_to_song_sample_matches_oracle": bool(np.array_equal(
+                    ctx.song_to_song(A[:1], A[:sub], "euclidean").cpu().numpy(), ref_chain)),
+            }
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

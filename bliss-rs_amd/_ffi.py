@@ -27,6 +27,8 @@ SIGNATURES = {
     "blissgpu_ctx_destroy": (C.c_int, [_vp]),
     "blissgpu_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "blissgpu_ctx_get_stream": (_vp, [_vp]),
+    "blissgpu_ctx_wait_stream": (C.c_int, [_vp, _vp]),
+    "blissgpu_ctx_signal_stream": (C.c_int, [_vp, _vp]),
     "blissgpu_ctx_set_workspace_limit": (C.c_int, [_vp, C.c_uint64]),
     "blissgpu_ctx_synchronize": (C.c_int, [_vp]),
     "blissgpu_feature_count": (C.c_uint32, [C.c_uint32]),

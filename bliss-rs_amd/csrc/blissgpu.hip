@@ -62,7 +62,7 @@ struct blissgpu_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // chroma chain + assembly (the caller-visible stream)
     hipStream_t aux_stream = nullptr;  // tempo / timbral / loudness chain, joined before the assembly
-    hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_stft = nullptr, ev_join = nullptr;
+    hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_stft = nullptr, ev_join = nullptr, ev_interop = nullptr;
     bool serial = false;               // BLISSGPU_SERIAL=1: single stream (clean per-kernel timings)
     int overlap_mode = 0;              // BLISSGPU_OVERLAP=1: start the per-song tails before the FFT-8192 kernel (experiment)
     uint64_t ws_limit = 96ull << 30;
@@ -536,6 +536,7 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_stft, hipEventDisableTiming);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_interop, hipEventDisableTiming);
     if (se != hipSuccess) { blissgpu_ctx_destroy(c); return fail(BLISSGPU_ERR_HIP, "aux stream/events", hipGetErrorString(se)); }
     if (const char* e = getenv("BLISSGPU_SERIAL")) c->serial = (e[0] == '1');
     if (const char* e = getenv("BLISSGPU_OVERLAP")) c->overlap_mode = atoi(e);
@@ -560,6 +561,7 @@ int blissgpu_ctx_destroy(blissgpu_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_stft) (void)hipEventDestroy(c->ev_stft);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_interop) (void)hipEventDestroy(c->ev_interop);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return BLISSGPU_OK;
@@ -572,6 +574,25 @@ int blissgpu_ctx_set_stream(blissgpu_ctx* c, void* s) {
     return BLISSGPU_OK;
 }
 void* blissgpu_ctx_get_stream(blissgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// Stream interop for hosts that keep their own streams (e.g. torch's current stream, NULL = the legacy default
+// stream): order the context's stream after / before work queued on another stream without a host synchronisation.
+int blissgpu_ctx_wait_stream(blissgpu_ctx* c, void* producer_stream) {
+    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_wait_stream", "ctx is NULL");
+    if ((hipStream_t)producer_stream == c->stream) return BLISSGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev_interop, (hipStream_t)producer_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_interop, 0));
+    return BLISSGPU_OK;
+}
+int blissgpu_ctx_signal_stream(blissgpu_ctx* c, void* consumer_stream) {
+    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_signal_stream", "ctx is NULL");
+    if ((hipStream_t)consumer_stream == c->stream) return BLISSGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev_interop, c->stream));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, c->ev_interop, 0));
+    return BLISSGPU_OK;
+}
 
 int blissgpu_ctx_set_workspace_limit(blissgpu_ctx* c, uint64_t bytes) {
     if (!c || bytes < (64ull << 20)) return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_set_workspace_limit", "limit < 64 MiB");

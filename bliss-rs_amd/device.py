@@ -31,8 +31,22 @@ class Context:
             self.bind_current_stream()
 
     def bind_current_stream(self):
+        """Launch on torch's current stream when it is a real stream; the legacy default stream (handle 0) cannot be
+        adopted (NULL means "the context's own stream"), so in that case every call below is ordered against it with
+        events instead (`_pre` / `_post`)."""
         s = self.torch.cuda.current_stream(self.device).cuda_stream
         _ffi.check(self._L.blissgpu_ctx_set_stream(self._h, C.c_void_p(s)))
+
+    def _torch_stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _pre(self):
+        """the context's stream waits for the inputs torch has queued on its current stream"""
+        _ffi.check(self._L.blissgpu_ctx_wait_stream(self._h, self._torch_stream()))
+
+    def _post(self):
+        """torch's current stream waits for the results queued on the context's stream"""
+        _ffi.check(self._L.blissgpu_ctx_signal_stream(self._h, self._torch_stream()))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -60,17 +74,21 @@ class Context:
             out = torch.empty((n, d), dtype=torch.float32, device=pcm.device)
         if status is None:
             status = torch.empty((n,), dtype=torch.int32, device=pcm.device)
+        self._pre()
         _ffi.check(self._L.blissgpu_analyze_batch_device(
             self._h, C.c_void_p(pcm.data_ptr()), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
             lengths.ctypes.data_as(C.POINTER(C.c_uint64)), n, features_version, C.c_void_p(out.data_ptr()),
             C.c_void_p(status.data_ptr())))
+        self._post()
         return out, status
 
     def synth_white_noise(self, pcm, offsets, lengths, first_song_index: int = 0):
         offsets, lengths = _u64(offsets), _u64(lengths)
+        self._pre()
         _ffi.check(self._L.blissgpu_synth_white_noise_device(
             self._h, C.c_void_p(pcm.data_ptr()), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
             lengths.ctypes.data_as(C.POINTER(C.c_uint64)), len(offsets), first_song_index))
+        self._post()
 
     def last_tuning(self, n):
         t = np.empty(n, np.float64)
@@ -112,8 +130,10 @@ class Context:
         if M is not None:
             M = M.contiguous()
             Mp = C.c_void_p(M.data_ptr())
+        self._pre()
         _ffi.check(self._L.blissgpu_pairwise_device(self._h, C.c_void_p(A.data_ptr()), n, C.c_void_p(B.data_ptr()), m,
                                                     d, _METRICS[metric], Mp, C.c_void_p(out.data_ptr()), out.stride(0)))
+        self._post()
         return out
 
     def pcm_s16_to_f32(self, pcm_s16, out=None):
@@ -123,9 +143,10 @@ class Context:
         pcm_s16 = pcm_s16.contiguous()
         if out is None:
             out = torch.empty(pcm_s16.shape, dtype=torch.float32, device=pcm_s16.device)
+        self._pre()
         _ffi.check(self._L.blissgpu_pcm_s16_to_f32_device(self._h, C.c_void_p(pcm_s16.data_ptr()), pcm_s16.numel(),
                                                           C.c_void_p(out.data_ptr())))
-        self.synchronize()
+        self._post()
         return out
 
     # ---- playlist ordering on device-resident feature matrices (src/playlist.rs:24-59, 256-326) ----
@@ -147,10 +168,11 @@ class Context:
 
         seeds, cand, M, Mp = self._pl_args(seeds, cand, M)
         out = self.torch.empty((cand.shape[0],), dtype=self.torch.float32, device=cand.device)
+        self._pre()
         _ffi.check(self._L.blissgpu_set_distance_device(self._h, C.c_void_p(seeds.data_ptr()), seeds.shape[0],
                                                         C.c_void_p(cand.data_ptr()), cand.shape[0], cand.shape[1],
                                                         _METRICS[metric], Mp, C.c_void_p(out.data_ptr())))
-        self.synchronize()  # the launch is on the context's stream, not torch's current stream
+        self._post()
         return out
 
     def closest_to_songs(self, seeds, cand, metric: str = "euclidean", M=None, return_distances=False):
@@ -162,9 +184,11 @@ class Context:
         n = cand.shape[0]
         order = torch.empty((n,), dtype=torch.int32, device=cand.device)
         dist = torch.empty((n,), dtype=torch.float32, device=cand.device)
+        self._pre()
         _ffi.check(self._L.blissgpu_closest_to_songs_device(self._h, C.c_void_p(seeds.data_ptr()), seeds.shape[0],
                                                             C.c_void_p(cand.data_ptr()), n, cand.shape[1], _METRICS[metric],
                                                             Mp, C.c_void_p(order.data_ptr()), C.c_void_p(dist.data_ptr())))
+        self._post()
         order = order.to(torch.int64)
         return (order, dist) if return_distances else order
 
@@ -176,9 +200,11 @@ class Context:
         seeds, cand, M, Mp = self._pl_args(seeds, cand, M)
         n = cand.shape[0]
         order = torch.empty((n,), dtype=torch.int32, device=cand.device)
+        self._pre()
         _ffi.check(self._L.blissgpu_song_to_song_device(self._h, C.c_void_p(seeds.data_ptr()), seeds.shape[0],
                                                         C.c_void_p(cand.data_ptr()), n, cand.shape[1], _METRICS[metric], Mp,
                                                         C.c_void_p(order.data_ptr())))
+        self._post()
         return order.to(torch.int64)
 
     # ---- profiling ----

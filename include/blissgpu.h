@@ -56,6 +56,12 @@ int blissgpu_ctx_destroy(blissgpu_ctx *ctx);
  * NULL restores the context's own stream. */
 int blissgpu_ctx_set_stream(blissgpu_ctx *ctx, void *hip_stream);
 void *blissgpu_ctx_get_stream(blissgpu_ctx *ctx);
+/* Ordering against streams the caller owns, without host synchronisation (hipStream_t passed as void*, NULL = the
+ * legacy default stream): wait_stream makes the context's stream wait for everything queued on producer_stream
+ * (inputs written there), signal_stream makes consumer_stream wait for everything queued on the context's stream
+ * (results read there). */
+int blissgpu_ctx_wait_stream(blissgpu_ctx *ctx, void *producer_stream);
+int blissgpu_ctx_signal_stream(blissgpu_ctx *ctx, void *consumer_stream);
 /* Upper bound for the scratch workspace in bytes (default 96 GiB); larger batches run in chunks. */
 int blissgpu_ctx_set_workspace_limit(blissgpu_ctx *ctx, uint64_t bytes);
 int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
