@@ -178,12 +178,21 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
                 q.y = sqrtf(sq.y);
             } else {
                 f2 p[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) p[u] = splat(0.0f);
                 constexpr int BODY = (D / 8) * 8;
-                static_for<BODY>([&](auto kc) { constexpr int k = decltype(kc)::value; p[k & 7] = p[k & 7] + term(kc); });
-                f2 sum = splat(0.0f);
-                sum = sum + (p[0] + p[4]);
+                f2 sum;
+                if (METRIC == METRIC_EUCLIDEAN && BODY >= 8) {
+                    // every term is a square (>= +0), so the reference's `0.0 + term` and `0.0 + (p0 + p4)` are exact
+                    // identities: start the eight partial sums at their first term (10 of 78 packed instructions less)
+                    static_for<8>([&](auto kc) { p[decltype(kc)::value] = term(kc); });
+                    static_for<BODY - 8>([&](auto kc) { constexpr int k = 8 + decltype(kc)::value; p[k & 7] = p[k & 7] + term(std::integral_constant<int, k>{}); });
+                    sum = p[0] + p[4];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) p[u] = splat(0.0f);
+                    static_for<BODY>([&](auto kc) { constexpr int k = decltype(kc)::value; p[k & 7] = p[k & 7] + term(kc); });
+                    sum = splat(0.0f);
+                    sum = sum + (p[0] + p[4]);
+                }
                 sum = sum + (p[1] + p[5]);
                 sum = sum + (p[2] + p[6]);
                 sum = sum + (p[3] + p[7]);

@@ -225,6 +225,53 @@ def test_workspace_chunking(bliss, oracle):
     assert np.array_equal(ref, got) and (status == 0).all()
 
 
+def test_mixed_duration_corpus_and_cue_slices(bliss, oracle):
+    """BASELINE configs[4] in miniature: a ragged corpus of 30 s .. 10 min songs generated in HBM, analysed under a
+    workspace limit that forces several chunks; a sample is checked against the oracle and against the same songs
+    analysed alone.  Second half: CUE-style tracks are (offset, length) slices of ONE decoded buffer,
+    adjacent and overlapping -- the batch descriptor takes them as they are, results equal separate buffers."""
+    import torch
+
+    rng = np.random.default_rng(21)
+    n = 36
+    lens = rng.integers(30 * 22050, 10 * 60 * 22050 + 1, n).astype(np.uint64)
+    lens[5] = 10 * 60 * 22050          # the longest allowed
+    lens[9] = 30 * 22050               # the shortest
+    offs = np.zeros(n, np.uint64)
+    offs[1:] = np.cumsum((lens + 63) // 64 * 64)[:-1]
+    total = int(offs[-1] + lens[-1])
+    ctx = bliss.Context(0)
+    ctx.set_workspace_limit(512 << 20)  # a few songs per chunk => many chunks
+    pcm = torch.empty(total, dtype=torch.float32, device="cuda")
+    ctx.synth_white_noise(pcm, offs, lens, first_song_index=500)
+    out, status = ctx.analyze(pcm, offs, lens, 2)
+    ctx.synchronize()
+    out = out.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all() and np.isfinite(out).all()
+    alone = bliss.Context(0)
+    for i in (5, 9, 20):
+        ref = oracle.song_analyze(oracle.white_noise(500 + i, int(lens[i])))
+        tol = _tol(int(lens[i]), 23)
+        assert (np.abs(out[i][1:] - ref[1:]) <= tol[1:]).all(), i
+        assert abs(out[i][0] - ref[0]) <= TEMPO_TOL, i
+        one, _ = alone.analyze(pcm, offs[i:i + 1], lens[i:i + 1], 2)
+        alone.synchronize()
+        assert np.array_equal(one.cpu().numpy()[0], out[i])   # chunk / batch composition does not matter
+
+    # ---- CUE-style slices of one buffer ----
+    disc = oracle.white_noise(900, 900_000)
+    tracks = [(0, 300_000), (300_000, 250_001), (550_001, 349_999), (100_000, 500_000), (891_808, 8192), (899_000, 1000)]
+    d_disc = torch.from_numpy(disc).cuda()
+    o = np.array([t[0] for t in tracks], np.uint64)
+    l = np.array([t[1] for t in tracks], np.uint64)
+    got, st = alone.analyze(d_disc, o, l, 2)
+    alone.synchronize()
+    got, st = got.cpu().numpy(), st.cpu().numpy()
+    assert st.tolist() == [0, 0, 0, 0, 0, 1]                  # the last "track" is shorter than 8192 samples
+    sep, _ = _run(alone, [disc[a:a + b] for a, b in tracks[:5]])
+    assert np.array_equal(got[:5], sep)
+
+
 # ---------------------------------------------------------------------------------------------
 # full-size (BASELINE configs[1] song size) properties
 # ---------------------------------------------------------------------------------------------
