@@ -7,7 +7,8 @@ bliss-rs / `bliss-audio` 0.13.0):
     Song.analyze / Song.analyze_with_options      src/song/mod.rs:403-508
     Analysis, AnalysisIndex, FeaturesVersion      src/song/mod.rs:102-371, src/lib.rs:151-187
     Decoder.{decode, song_from_path, analyze_paths}  src/song/decoder.rs:115-333
-    euclidean / cosine / mahalanobis distance     src/playlist.rs:65-142
+    euclidean / cosine / mahalanobis distance, closest_to_songs, song_to_song, dedup, ...   src/playlist.rs
+    library.{load_feature_matrix, load_songs, store_song}   feature table of src/library.rs:500-531, 1355-1372, 1560-1630
 
 All compute goes through the C ABI of include/blissgpu.h (hand-written HIP kernels for gfx950);
 there is no CPU fallback.
@@ -18,6 +19,7 @@ from .song import (  # noqa: F401
     AnalysisOptions, BlissError, DecodingError, FeaturesVersion, ProviderError, Song, analyze_batch)
 from .decoder import Decoder, PreAnalyzedSong, RawPcmDecoder  # noqa: F401
 from . import playlist  # noqa: F401
+from . import library  # noqa: F401
 from .device import Context  # noqa: F401
 
 __version__ = "0.1.0"

@@ -163,3 +163,26 @@ def test_device_resident_forms_and_full_library_size(bliss, oracle):
         assert chain[k] == int(np.argmin(dk)), k  # np.argmin = first minimum
         alive[chain[k]] = False
         cur = X_h[chain[k]][None, :]
+
+
+def test_library_drives_the_ordering_kernels(bliss, oracle, tmp_path):
+    """an existing feature table feeds the device matrix directly -- no re-analysis -- and the order is
+    the one the Song-object API produces."""
+    import torch
+
+    rng = np.random.default_rng(8)
+    db = str(tmp_path / "lib.db")
+    bliss.library.create_schema(db)
+    songs = [bliss.Song(path=f"/m/{i:04d}.flac", title=f"t{i}", artist=f"a{i % 7}",
+                        analysis=bliss.Analysis(rng.uniform(-1, 1, 23).astype(np.float32), bliss.FeaturesVersion.LATEST))
+             for i in range(400)]
+    bliss.library.store_songs(db, songs)
+    ids, paths, m = bliss.library.load_feature_matrix(db)
+    ctx = bliss.Context(0)
+    X = torch.from_numpy(m).cuda()
+    W = torch.from_numpy(oracle.feature_weights(2)).cuda()
+    order = ctx.closest_to_songs(X[:2], X, "mahalanobis", W).cpu().numpy()
+    via_songs = bliss.playlist.closest_to_songs(songs[:2], songs, bliss.playlist.MahalanobisBuilder(oracle.feature_weights(2)))
+    assert [paths[i] for i in order] == [s.path for s in via_songs]
+    chain = ctx.song_to_song(X[:1], X, "euclidean").cpu().numpy()
+    assert np.array_equal(chain, oracle.song_to_song(m[:1], m, "euclidean"))
