@@ -28,7 +28,11 @@ __global__ __launch_bounds__(256) void pcm_stats_kernel(const float* __restrict_
             const uint64_t base0 = (uint64_t)q0 * 256;
             float4 v[PCM_TILE_BLOCKS / 4];
 #pragma unroll
-            for (int i = 0; i < PCM_TILE_BLOCKS / 4; i++) v[i] = *reinterpret_cast<const float4*>(x + base0 + 256 * i + 4 * lane);
+            for (int i = 0; i < PCM_TILE_BLOCKS / 4; i++) {  // streamed once: non-temporal, the FFT kernels own the L2
+                typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                const f32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(x + base0 + 256 * i + 4 * lane));
+                v[i] = make_float4(q.x, q.y, q.z, q.w);
+            }
             uint32_t carry = (x[base0 > 0 ? base0 - 1 : 0] > 0.0f) ? 1u : 0u;  // positivity of the sample before the block
             float ss[PCM_TILE_BLOCKS / 4];
             uint32_t zc[PCM_TILE_BLOCKS / 4];
