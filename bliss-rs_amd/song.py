@@ -155,7 +155,10 @@ class Analysis:
 
 
 def _as_pcm(sample_array) -> np.ndarray:
-    return np.ascontiguousarray(sample_array, dtype=np.float32).reshape(-1)
+    a = np.asarray(sample_array)
+    if a.dtype == np.int16:  # s16 PCM: FFmpeg's s16 -> flt conversion (exact in f32)
+        return (a.astype(np.float32) / np.float32(32768.0)).reshape(-1)
+    return np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
 
 
 def analyze_batch(sample_arrays: Sequence[np.ndarray], options: Optional[AnalysisOptions] = None):
