@@ -238,6 +238,8 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
     // a song's few hot histogram lines would otherwise serialise at the L2
     __shared__ uint32_t lhist[LHIST_BINS];
     __shared__ uint32_t lhist_base;
+    __shared__ uint16_t peak_list[PIP_MAX_PER_FRAME + 2];
+    __shared__ uint32_t peak_count;
     __shared__ f2 tw256[256];  // W_256^(m2*j1) at [16 j1 + m2] (pass-2 twiddles, broadcast reads)
     {
         const float2 a = tw[32 * (((threadIdx.x >> 4) * (threadIdx.x & 15)) & 255)];
@@ -391,6 +393,7 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
         if (t == 0) mags[2048] = m_mid;
         if (t >= 1 && t < CBINS_PAD - 4096) mags[4096 + t] = 0.0f;  // zero padding after bin 4096
         if (lane_id() == 0) red[wave_id()] = mx;
+        if (t == 0) peak_count = 0;
         __syncthreads();
         // The spectrogram row goes to HBM from the LDS copy as 16-byte stores (5 per thread instead of 18 scalar
         // ones).  They are issued BEHIND the next frame's loads: vmcnt retires in order, so the wait for those
@@ -419,22 +422,36 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
             __syncthreads();
         }
         const uint32_t lbase = lhist_base;
-        // ---- pip_track pass 1: count peaks by coarse magnitude bin.  Cheap test by every lane, the
-        // peaks (about a third of the bins) are compacted so the f64 part runs on full wavefronts ----
+        // ---- pip_track pass 1: count peaks by coarse magnitude bin.  Every lane tests its six bins; the peaks (about a
+        // third of the bins) are compacted through an LDS list so the interpolation arithmetic runs on dense
+        // wavefronts instead of six times under a one-third-full exec mask ----
         const double ref = 0.1 * (double)mx;
         const float thr = ref_floor_f32(ref);
         if (ABL != 1) {
+            uint32_t hits = 0;  // bit j: bin t + 256 j is a peak
 #pragma unroll
             for (int j = 0; j < 6; j++) {
                 const int c = t + 256 * j;
-                if (c < PIP_LO || c > PIP_HI) continue;
-                const float sb = mags[c - 1], se = mags[c], sa = mags[c + 1];
-                if (sa <= se && sb < se && se > thr) {
-                    const uint32_t b = peak_coarse_bin(sb, se, sa, ref, c), rel = b - lbase;
-                    if (ABL == 13) { if (rel == 0x7fffffffu) lhist[0] = 1; }
-                    else if (rel < (uint32_t)LHIST_BINS) atomicAdd(&lhist[rel], 1u);
-                    else atomicAdd(&hist[b], 1u);
-                }
+                const float sb = mags[c > 0 ? c - 1 : 0], se = mags[c], sa = mags[c + 1];
+                const bool pk = c >= PIP_LO && c <= PIP_HI && sa <= se && sb < se && se > thr;
+                hits |= (pk ? 1u : 0u) << j;
+            }
+            const uint32_t mine = (uint32_t)__popc(hits);
+            const uint32_t incl = wave_scan_incl_u32(mine);
+            uint32_t wbase = 0;
+            if (lane_id() == 63) wbase = atomicAdd(&peak_count, incl);  // the wave's slice of the list
+            uint32_t pos = __shfl(wbase, 63, WAVE) + incl - mine;
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+                if ((hits >> j) & 1u) peak_list[pos++] = (uint16_t)(t + 256 * j);
+            __syncthreads();
+            const uint32_t n_peaks = peak_count;
+            for (uint32_t i = t; i < n_peaks; i += 256) {
+                const int c = peak_list[i];
+                const uint32_t b = peak_coarse_bin(mags[c - 1], mags[c], mags[c + 1], ref, c), rel = b - lbase;
+                if (ABL == 13) { if (rel == 0x7fffffffu) lhist[0] = 1; }
+                else if (rel < (uint32_t)LHIST_BINS) atomicAdd(&lhist[rel], 1u);
+                else atomicAdd(&hist[b], 1u);
             }
         }
         if (has_next) {
