@@ -91,11 +91,12 @@ def main():
     out = torch.empty((n, d), dtype=torch.float32, device="cuda")
     status = torch.empty((n,), dtype=torch.int32, device="cuda")
     global_idx = np.arange(rank * n, rank * n + n)
+    global_idx_dev = torch.as_tensor(global_idx, device="cuda")  # uploaded once, not per step
 
     def step():
         ctx.analyze(pcm, offs, lens, 2, out=out, status=status)
         if world > 1:
-            return all_gather_features(out, global_idx, world * n)
+            return all_gather_features(out, global_idx_dev, world * n, n_local_max=n)
         return out
 
     def fence():

@@ -28,21 +28,27 @@ def shard_songs(lengths: Sequence[int], world_size: int) -> List[np.ndarray]:
     return [np.array(sorted(s), dtype=np.int64) for s in shards]
 
 
-def all_gather_features(local_rows, local_indices, n_total: int, group=None):
+def all_gather_features(local_rows, local_indices, n_total: int, group=None, n_local_max=None):
     """All-gather ragged [n_local, d] feature blocks and scatter them to their global rows.
 
     local_rows: torch tensor [n_local, d] (CUDA -> RCCL, CPU -> gloo); local_indices: global song index
-    of each local row.  Returns a [n_total, d] tensor on the same device, identical on every rank."""
+    of each local row.  Returns a [n_total, d] tensor on the same device, identical on every rank.
+    n_local_max: the largest shard size if the caller knows it (e.g. from shard_songs, which every rank computes
+    identically); it saves the count exchange and its host synchronisation."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     d = local_rows.shape[1]
     dev = local_rows.device
-    idx = torch.as_tensor(np.asarray(local_indices, dtype=np.int64), device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=dev), group=group)
-    n_max = int(max(int(c.item()) for c in counts))
+    idx = local_indices.to(dev) if torch.is_tensor(local_indices) else torch.as_tensor(np.asarray(local_indices, dtype=np.int64), device=dev)
+    if n_local_max is None:
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=dev), group=group)
+        n_max = int(max(int(c.item()) for c in counts))
+    else:
+        n_max = int(n_local_max)
+        assert local_rows.shape[0] <= n_max
     # pad to the largest shard: one fixed-size all-gather (latency-bound at these sizes: <= ~1 MB)
     pad_rows = torch.zeros((n_max, d), dtype=local_rows.dtype, device=dev)
     pad_rows[: local_rows.shape[0]] = local_rows

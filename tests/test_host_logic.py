@@ -146,6 +146,10 @@ rows = np.stack([O.song_analyze(O.white_noise(int(i), lengths[int(i)])) for i in
 full = all_gather_features(torch.from_numpy(rows), mine, len(lengths))
 ref = np.stack([O.song_analyze(O.white_noise(i, n)) for i, n in enumerate(lengths)])
 assert np.array_equal(full.numpy(), ref), "gathered matrix differs"
+# the fast path bench.py uses: shard sizes known on every rank (shard_songs is deterministic), indices already a tensor
+n_max = max(len(s) for s in shard_songs(lengths, world))
+full2 = all_gather_features(torch.from_numpy(rows), torch.as_tensor(mine), len(lengths), n_local_max=n_max)
+assert np.array_equal(full2.numpy(), ref), "gathered matrix differs (known shard sizes)"
 lo, hi = row_block(len(lengths), rank, world)
 D = O.pairwise(ref[lo:hi], ref, "euclidean")
 parts = [None] * world
