@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblissgpu.so")
+# BLISSGPU_LIB: developer aid for A/B timing of two builds of the library on the same box (never a CPU path)
+LIB_PATH = os.environ.get("BLISSGPU_LIB") or os.path.join(_HERE, "libblissgpu.so")
 
 OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_NAN = 0, 1, 2, 3, 4, 5
 SONG_OK, SONG_TOO_SHORT = 0, 1
