@@ -392,7 +392,13 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
         }
         if (t == 0) mags[2048] = m_mid;
         if (t >= 1 && t < CBINS_PAD - 4096) mags[4096 + t] = 0.0f;  // zero padding after bin 4096
-        if (lane_id() == 0) red[wave_id()] = mx;
+        {
+            // the slot index is re-derived from the thread id inside the loop: kept live across the whole frame loop
+            // it was the first register to be spilled, and its reload forced a vmcnt(0) drain per frame
+            int slot = t >> 6;
+            asm volatile("" : "+v"(slot));
+            if (lane_id() == 0) red[slot] = mx;
+        }
         if (t == 0) peak_count = 0;
         __syncthreads();
         // The spectrogram row goes to HBM from the LDS copy as 16-byte stores (5 per thread instead of 18 scalar
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
 void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.tiles_c == 0) return;
     static const int abl = getenv("BLISSGPU_ABL") ? atoi(getenv("BLISSGPU_ABL")) : 0;
-    static const int occ = getenv("BLISSGPU_STFT_OCC") ? atoi(getenv("BLISSGPU_STFT_OCC")) : 3;
+    static const int occ = getenv("BLISSGPU_STFT_OCC") ? atoi(getenv("BLISSGPU_STFT_OCC")) : 4;  // 4 workgroups/CU: 128 VGPRs, no spills (-6 % vs 3)
 #define LAUNCH_STFT(A) hipLaunchKernelGGL((stft8192_kernel<A, 3>), dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, \
                                           b.pfx_c, t.hann8192, t.tw8192, t.tw_p1, w.spec, w.frame_max, w.h1)
     if (abl == 1) LAUNCH_STFT(1);
