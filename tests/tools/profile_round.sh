@@ -5,7 +5,7 @@
 R=$PWD; TAG=${TAG:-r01}; O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 600 $O/bench.json
 cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py --no-cpu-baseline --no-host-feed > $O/trace.log 2>&1; echo "trace rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py --no-cpu-baseline --no-host-feed --no-playlist > $O/trace.log 2>&1; echo "trace rc=$?"
 cd $R
 DB=$(find $O/trace -name "*.db" | head -1)
 python tests/tools/rocpd_stats.py $DB > $O/${TAG}_bench_1024songs.kernel_stats.txt; head -16 $O/${TAG}_bench_1024songs.kernel_stats.txt
