@@ -67,7 +67,7 @@ struct blissgpu_ctx {
     int overlap_mode = 0;              // BLISSGPU_OVERLAP=1: start the per-song tails before the FFT-8192 kernel (experiment)
     uint64_t ws_limit = 96ull << 30;
     // tables
-    float2 *tw8192 = nullptr, *tw512 = nullptr, *tw_p1 = nullptr;
+    float2 *tw8192 = nullptr, *tw512 = nullptr;
     float *hann8192 = nullptr, *hannz512 = nullptr, *bt_rwv = nullptr, *bt_dfwv = nullptr;
     double* chroma_bank = nullptr;
     DeviceTables tables{};
@@ -133,12 +133,6 @@ int build_tables(blissgpu_ctx* c) {
         const double a = -2.0 * M_PI * (double)k / 512.0;
         tw5[k] = make_float2((float)cos(a), (float)sin(a));
     }
-    std::vector<float2> twp1(16 * 256);
-    for (int k1 = 0; k1 < 16; k1++)
-        for (int t = 0; t < 256; t++) {
-            const double a = -2.0 * M_PI * (double)(t * k1) / 4096.0;
-            twp1[k1 * 256 + t] = make_float2((float)cos(a), (float)sin(a));
-        }
     // periodic Hann, evaluated in f32 exactly as src/utils.rs:37-39
     std::vector<float> hann(8192), hannz(512), rwv(BT_LAGLEN), dfwv(BT_WINLEN);
     // Both device tables hold HALF the window: the real-input split needs X = (A + P) / 2, and a power-of-two scale
@@ -158,7 +152,6 @@ int build_tables(blissgpu_ctx* c) {
     int rc;
     if ((rc = upload(&c->tw8192, tw8))) return rc;
     if ((rc = upload(&c->tw512, tw5))) return rc;
-    if ((rc = upload(&c->tw_p1, twp1))) return rc;
     if ((rc = upload(&c->hann8192, hann))) return rc;
     if ((rc = upload(&c->hannz512, hannz))) return rc;
     if ((rc = upload(&c->bt_rwv, rwv))) return rc;
@@ -168,7 +161,7 @@ int build_tables(blissgpu_ctx* c) {
     launch_chroma_bank(c->chroma_bank, c->own_stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->own_stream));
-    c->tables = DeviceTables{c->tw8192, c->tw512, c->tw_p1, c->hann8192, c->hannz512, c->chroma_bank, c->bt_rwv, c->bt_dfwv};
+    c->tables = DeviceTables{c->tw8192, c->tw512, c->hann8192, c->hannz512, c->chroma_bank, c->bt_rwv, c->bt_dfwv};
     return BLISSGPU_OK;
 }
 
@@ -552,7 +545,7 @@ int blissgpu_ctx_destroy(blissgpu_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& v : c->events)
         for (auto& ev : v) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    (void)hipFree(c->tw8192); (void)hipFree(c->tw512); (void)hipFree(c->tw_p1); (void)hipFree(c->hann8192); (void)hipFree(c->hannz512);
+    (void)hipFree(c->tw8192); (void)hipFree(c->tw512); (void)hipFree(c->hann8192); (void)hipFree(c->hannz512);
     (void)hipFree(c->bt_rwv); (void)hipFree(c->bt_dfwv); (void)hipFree(c->chroma_bank);
     c->slab.release(); c->desc.release(); c->dbg_tuning.release(); c->dbg_nbpms.release();
     if (c->h_desc) (void)hipHostFree(c->h_desc);

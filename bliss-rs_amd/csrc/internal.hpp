@@ -69,7 +69,6 @@ struct TempoState {
 struct DeviceTables {   // constant tables, built once per context
     const float2* tw8192;     // exp(-2*pi*i*k/8192), k < 8192
     const float2* tw512;      // exp(-2*pi*i*k/512),  k < 512
-    const float2* tw_p1;      // [16][256]: exp(-2*pi*i*t*k1/4096) at [k1*256 + t] (pass-1 twiddles of the 4096-point FFT, coalesced)
     const float* hann8192;    // periodic Hann, src/utils.rs:37-39
     const float* hannz512;    // hanningz, src/aubio.rs:151-154
     const double* chroma_bank;// [N_TUNING+1][BANK_ROWS][CBINS_PAD] chroma filters (zero padded); slot N_TUNING = tuning 0.0

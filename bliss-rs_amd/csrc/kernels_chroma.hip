@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
                                                        const uint32_t* __restrict__ pfx_c,
                                                        const float* __restrict__ hann,
                                                        const float2* __restrict__ tw,
-                                                       const float2* __restrict__ tw_p1, float* __restrict__ spec,
+                                                       float* __restrict__ spec,
                                                        float* __restrict__ frame_max, uint32_t* __restrict__ h1) {
     __shared__ f2 lds[STFT_LDS];
     __shared__ float red[4];
@@ -480,7 +480,7 @@ void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, 
     static const int abl = getenv("BLISSGPU_ABL") ? atoi(getenv("BLISSGPU_ABL")) : 0;
     static const int occ = getenv("BLISSGPU_STFT_OCC") ? atoi(getenv("BLISSGPU_STFT_OCC")) : 4;  // 4 workgroups/CU: 128 VGPRs, no spills (-6 % vs 3)
 #define LAUNCH_STFT(A) hipLaunchKernelGGL((stft8192_kernel<A, 3>), dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, \
-                                          b.pfx_c, t.hann8192, t.tw8192, t.tw_p1, w.spec, w.frame_max, w.h1)
+                                          b.pfx_c, t.hann8192, t.tw8192, w.spec, w.frame_max, w.h1)
     if (abl == 1) LAUNCH_STFT(1);
     else if (abl == 2) LAUNCH_STFT(2);
     else if (abl == 3) LAUNCH_STFT(3);
@@ -499,7 +499,7 @@ void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, 
     else if (abl == 17) LAUNCH_STFT(17);
     else if (occ == 4)
         hipLaunchKernelGGL((stft8192_kernel<0, 4>), dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs,
-                           b.pfx_c, t.hann8192, t.tw8192, t.tw_p1, w.spec, w.frame_max, w.h1);
+                           b.pfx_c, t.hann8192, t.tw8192, w.spec, w.frame_max, w.h1);
     else LAUNCH_STFT(0);
 #undef LAUNCH_STFT
 }
