@@ -27,7 +27,7 @@ constexpr int PIP_LO = 57, PIP_HI = 1483; // centre bins visited by pip_track at
 constexpr int PIP_MAX_PER_FRAME = 714;    // peaks cannot be adjacent: ceil(1427/2)
 constexpr int H1_BINS = 8192;             // coarse magnitude histogram: f32 bit pattern >> 18
 constexpr int BT_WINLEN = 512, BT_STEP = 128, BT_LAGLEN = 128;  // src/aubio.rs:1337-1341, 920-922
-constexpr int F512_TILE = 256;            // FFT-512 frames per workgroup (16 lane-groups x 16 consecutive frames)
+constexpr int F512_TILE = 512;            // FFT-512 frames per workgroup (16 lane-groups x 32 consecutive frames + 1 halo frame each)
 constexpr int CH_TILE = 64;               // chroma frames per workgroup in the contraction kernel
 constexpr int STFT_TILE = 16;             // chroma frames per workgroup in the STFT kernel
 
