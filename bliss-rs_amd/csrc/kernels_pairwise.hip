@@ -39,6 +39,32 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 __device__ __forceinline__ f2 splat(float x) { f2 r; r.x = x; r.y = x; return r; }
 
+// Correctly rounded sqrt (what Rust's f32::sqrt / the oracle's sqrtf return) for the two halves of a pair.
+// v_sqrt_f32 is within 1 ulp; the exact residuals against the two neighbours (one FMA each) pick the correctly
+// rounded value -- the compiler's own sqrtf expansion minus its input scaling for x < 2^-96, which v_sqrt_f32
+// needs because it does not take denormal inputs.  The rare tiny inputs (and only those) use sqrtf; 0, inf and
+// NaN come out right (NaN residuals fail both comparisons).
+__device__ __forceinline__ float sqrt_rn_fast(float x) {
+    const float r = __builtin_amdgcn_sqrtf(x);
+    const float rd = __uint_as_float(__float_as_uint(r) - 1u), ru = __uint_as_float(__float_as_uint(r) + 1u);
+    const float vp = __builtin_fmaf(-rd, r, x), vs = __builtin_fmaf(-ru, r, x);
+    float o = (vp <= 0.0f) ? rd : r;
+    o = (vs > 0.0f) ? ru : o;
+    return o;
+}
+__device__ __forceinline__ f2 sqrt_rn2(f2 x) {
+    f2 r;
+    const bool tiny = (x.x < 0x1p-96f && x.x != 0.0f) || (x.y < 0x1p-96f && x.y != 0.0f);
+    if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {  // wave-uniform
+        r.x = sqrtf(x.x);
+        r.y = sqrtf(x.y);
+    } else {
+        r.x = sqrt_rn_fast(x.x);
+        r.y = sqrt_rn_fast(x.y);
+    }
+    return r;
+}
+
 // (a, a) - b and (a, a) * b where a is the LO (HI = false) or HI half of a register pair: the broadcast
 // is an op_sel modifier of the packed instruction instead of two v_mov per element
 template <bool HI>
@@ -174,8 +200,7 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
                     t[jj] = acc;
                 }
                 const f2 sq = unrolled_dot2<D>([&](int k) { return t[k]; }, [&](int k) { return v[k]; });
-                q.x = sqrtf(sq.x);
-                q.y = sqrtf(sq.y);
+                q = sqrt_rn2(sq);
             } else {
                 f2 p[8];
                 constexpr int BODY = (D / 8) * 8;
@@ -202,8 +227,7 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
                 } else if (ABL == 1) {
                     q = sum;
                 } else {
-                    q.x = sqrtf(sum.x);
-                    q.y = sqrtf(sum.y);
+                    q = sqrt_rn2(sum);
                 }
             }
             res[2 * h] = q.x;
