@@ -187,6 +187,7 @@ size_t song_ws_bytes(const SongDesc& d) {
     b += (size_t)d.n_c * (CBINS_PAD * 4 + 4);
     b += (size_t)H1_BINS * 4 + N_TUNING * 4 + sizeof(TuningState) + sizeof(TempoState);
     b += (size_t)d.n_c * PIP_MAX_PER_FRAME * 9;
+    b += (size_t)d.n_c * (PIP_MAX_PER_FRAME * 4 + 4);
     b += ((size_t)d.n_c / CH_TILE + 1) * 80;
     b += ((size_t)d.n_b / BT_STEP + 2) * 8;
     return b + 4096;
@@ -271,6 +272,7 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
         m.take<float>(tot_c * CBINS_PAD + 64); m.take<float>(tot_c);
         m.take<uint32_t>((size_t)ns * H1_BINS); m.take<uint32_t>((size_t)ns * N_TUNING);
         m.take<TuningState>(ns);
+        m.take<uint32_t>(tot_cand); m.take<uint32_t>(tot_c);
         m.take<double>(tot_cand); m.take<uint8_t>(tot_cand);
         m.take<double>((size_t)b.tiles_ct * 10 + 16);
         m.take<TempoState>(ns);
@@ -289,6 +291,7 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs,
     w.spec = m.take<float>(tot_c * CBINS_PAD + 64); w.frame_max = m.take<float>(tot_c);
     w.h1 = m.take<uint32_t>((size_t)ns * H1_BINS); w.hist100 = m.take<uint32_t>((size_t)ns * N_TUNING);
     w.tuning = m.take<TuningState>(ns);
+    w.peak_rec = m.take<uint32_t>(tot_cand); w.peak_cnt = m.take<uint32_t>(tot_c);
     w.cand_mag = m.take<double>(tot_cand); w.cand_pb = m.take<uint8_t>(tot_cand);
     w.chroma_part = m.take<double>((size_t)b.tiles_ct * 10 + 16);
     w.tempo = m.take<TempoState>(ns);

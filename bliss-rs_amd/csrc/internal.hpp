@@ -118,6 +118,8 @@ struct Workspace {
     uint32_t* h1;           // [n_songs][H1_BINS]
     uint32_t* hist100;      // [n_songs][N_TUNING]
     TuningState* tuning;    // [n_songs]
+    uint32_t* peak_rec;     // [total_c][PIP_MAX_PER_FRAME] per-peak records written by the STFT kernel (see peak_record())
+    uint32_t* peak_cnt;     // [total_c] records per frame
     double* cand_mag;       // [total_cand]
     uint8_t* cand_pb;       // [total_cand]
     double* chroma_part;    // [total chroma tiles][10] partial sums of interval features

@@ -186,6 +186,13 @@ __device__ __forceinline__ int peak_pitch_bin_f32(float sb, float se, float sa, 
     return idx < 0 ? 0 : (idx > N_TUNING - 1 ? N_TUNING - 1 : idx);
 }
 
+// One 32-bit record per peak, written by the STFT kernel while the frame is still in LDS and consumed by tuning
+// pass 2 (which then never re-scans the spectrogram): exact coarse magnitude bin (13 bits) | pitch-residue bin + 1
+// (7 bits, 0 = the f32 evaluation was not provable, take the f64 path) | centre bin (11 bits).
+__device__ __forceinline__ uint32_t peak_record(uint32_t coarse, int pitch_bin_or_neg, int c) {
+    return (coarse << 18) | ((uint32_t)(pitch_bin_or_neg + 1) << 11) | (uint32_t)c;
+}
+
 // ------------------------------------------------------------------------------------------------
 // STFT 8192 / hop 2205
 //
@@ -230,7 +237,8 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
                                                        const float* __restrict__ hann,
                                                        const float2* __restrict__ tw,
                                                        float* __restrict__ spec,
-                                                       float* __restrict__ frame_max, uint32_t* __restrict__ h1) {
+                                                       float* __restrict__ frame_max, uint32_t* __restrict__ h1,
+                                                       uint32_t* __restrict__ peak_rec, uint32_t* __restrict__ peak_cnt) {
     __shared__ f2 lds[STFT_LDS];
     __shared__ float red[4];
     // peaks are first counted in an LDS window of the coarse-magnitude histogram (a frame's peaks lie
@@ -452,9 +460,13 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
                 if ((hits >> j) & 1u) peak_list[pos++] = (uint16_t)(t + 256 * j);
             __syncthreads();
             const uint32_t n_peaks = peak_count;
+            uint32_t* __restrict__ recs = peak_rec + (sd.c_off + f) * (size_t)PIP_MAX_PER_FRAME;
+            if (t == 0) peak_cnt[sd.c_off + f] = n_peaks;
             for (uint32_t i = t; i < n_peaks; i += 256) {
                 const int c = peak_list[i];
-                const uint32_t b = peak_coarse_bin(mags[c - 1], mags[c], mags[c + 1], ref, c), rel = b - lbase;
+                const float sb = mags[c - 1], se = mags[c], sa = mags[c + 1];
+                const uint32_t b = peak_coarse_bin(sb, se, sa, ref, c), rel = b - lbase;
+                recs[i] = peak_record(b, peak_pitch_bin_f32(sb, se, sa, c), c);
                 if (ABL == 13) { if (rel == 0x7fffffffu) lhist[0] = 1; }
                 else if (rel < (uint32_t)LHIST_BINS) atomicAdd(&lhist[rel], 1u);
                 else atomicAdd(&hist[b], 1u);
@@ -480,7 +492,7 @@ void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, 
     static const int abl = getenv("BLISSGPU_ABL") ? atoi(getenv("BLISSGPU_ABL")) : 0;
     static const int occ = getenv("BLISSGPU_STFT_OCC") ? atoi(getenv("BLISSGPU_STFT_OCC")) : 4;  // 4 workgroups/CU: 128 VGPRs, no spills (-6 % vs 3)
 #define LAUNCH_STFT(A) hipLaunchKernelGGL((stft8192_kernel<A, 3>), dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, \
-                                          b.pfx_c, t.hann8192, t.tw8192, w.spec, w.frame_max, w.h1)
+                                          b.pfx_c, t.hann8192, t.tw8192, w.spec, w.frame_max, w.h1, w.peak_rec, w.peak_cnt)
     if (abl == 1) LAUNCH_STFT(1);
     else if (abl == 2) LAUNCH_STFT(2);
     else if (abl == 3) LAUNCH_STFT(3);
@@ -499,7 +511,7 @@ void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, 
     else if (abl == 17) LAUNCH_STFT(17);
     else if (occ == 4)
         hipLaunchKernelGGL((stft8192_kernel<0, 4>), dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs,
-                           b.pfx_c, t.hann8192, t.tw8192, w.spec, w.frame_max, w.h1);
+                           b.pfx_c, t.hann8192, t.tw8192, w.spec, w.frame_max, w.h1, w.peak_rec, w.peak_cnt);
     else LAUNCH_STFT(0);
 #undef LAUNCH_STFT
 }
@@ -562,37 +574,23 @@ void launch_tune_select(const Batch& b, const Workspace& w, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 constexpr int P2_SLOW_CAP = 1024;  // per-wave list of peaks that need the f64 path
 constexpr int P2_FRAMES_PER_WAVE = CH_TILE / 4;
-constexpr int P2_FAST_CAP = 768;   // per-wave list of one frame's peaks at or above the median's coarse bins (<= 714)
-constexpr int P2_C0 = 56;          // first bin held in registers (multiple of 4, = PIP_LO - 1)
-constexpr int P2_CHUNKS = 6;       // float4 chunks per lane: bins 56 .. 56 + 4*64*6 - 1 = 1591 >= PIP_HI + 1
 
-// whole-wave rotations by one lane (GFX9 DPP wave_ror:1 / wave_rol:1)
-__device__ __forceinline__ float wave_ror1(float v) {  // lane l <- lane l - 1, lane 0 <- lane 63
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float wave_rol1(float v) {  // lane l <- lane l + 1, lane 63 <- lane 0
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134, 0xF, 0xF, false));
-}
-
-// A wave owns a frame at a time: the 1536 magnitudes that can hold peaks are loaded as six 16-byte loads per lane
-// (the next frame's are in flight meanwhile), neighbours come from lane rotations, and a peak is classified with
-// two thresholds before any arithmetic: the interpolated magnitude lies in [se, 1.25 se], so se < 0.8 E(b_lo) is
-// certainly below the median's coarse bins (dropped: half of all peaks) and se >= E(b_hi + 1) certainly above.
-// Peaks at or above the median's bins are compacted into an LDS list so the pitch-bin arithmetic runs on dense
-// wavefronts; the few that need f64 (guard-band hits, candidates inside the median's bins) go to a second list
-// that is flushed across frames.
+// A wave owns a frame at a time and walks the frame's peak records: peaks above the median's coarse bins add their
+// (pre-computed) pitch bin to the histogram, peaks below are dropped, and the few that need f64 -- records without a
+// provable pitch bin, candidates inside the median's bins -- are queued in an LDS list that is flushed across
+// frames on dense wavefronts, reading their three magnitudes back from the spectrogram.
 __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                          const uint32_t* __restrict__ pfx_ct,
                                                          const float* __restrict__ spec,
                                                          const float* __restrict__ frame_max,
+                                                         const uint32_t* __restrict__ peak_rec,
+                                                         const uint32_t* __restrict__ peak_cnt,
                                                          TuningState* __restrict__ tuning,
                                                          uint32_t* __restrict__ hist100,
                                                          double* __restrict__ cand_mag,
                                                          uint8_t* __restrict__ cand_pb) {
     __shared__ uint32_t hist[N_TUNING];
     __shared__ uint32_t slow_list[4][P2_SLOW_CAP];  // (frame slot << 16) | centre bin
-    __shared__ uint32_t slow_count[4];
-    __shared__ uint16_t fast_list[4][P2_FAST_CAP];  // (kind << 12) | centre bin; kind 1 = above, 2 = inside
     const uint32_t s = find_segment(pfx_ct, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
     const uint32_t tile = blockIdx.x - pfx_ct[s];
@@ -601,14 +599,10 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
     const uint32_t b_lo = ts->b_lo, b_hi = ts->b_hi;
     if (ts->n_peaks == 0) return;
     if (tid < N_TUNING) hist[tid] = 0;
-    if (lane == 0) slow_count[wave] = 0;
     __syncthreads();
-    // E(b) = smallest float of coarse bin b
-    const float t_lo = __uint_as_float(b_lo << 18) * 0.79999f;
-    const float t_hi = (b_hi + 1 < (uint32_t)H1_BINS) ? __uint_as_float((b_hi + 1) << 18) : __builtin_inff();
+    uint32_t n_slow = 0;  // wave-uniform
 
     auto flush = [&]() {
-        const uint32_t n_slow = slow_count[wave];
         for (uint32_t i = lane; i < n_slow; i += WAVE) {
             const uint32_t e = slow_list[wave][i];
             const int c = (int)(e & 0xFFFFu);
@@ -628,92 +622,36 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) slow_count[wave] = 0;
-        __builtin_amdgcn_wave_barrier();
+        n_slow = 0;
     };
-    auto wave_push = [&](bool want, uint32_t value, auto store, uint32_t& count) {  // count is wave-uniform
-        const uint64_t mask = __ballot(want);
-        if (mask) {
-            if (want) store(count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), value);
-            count += (uint32_t)__popcll(mask);
-        }
-    };
-    auto load_row = [&](uint32_t f, float4 (&q)[P2_CHUNKS], float& edge) {
-        const float* row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
-#pragma unroll
-        for (int k = 0; k < P2_CHUNKS; k++) q[k] = *reinterpret_cast<const float4*>(row + P2_C0 + 4 * (lane + 64 * k));
-        edge = row[P2_C0 - 1];
-    };
-
-    float4 q[P2_CHUNKS], qn[P2_CHUNKS];
-    float edge = 0.0f, edge_n = 0.0f;
-    const uint32_t f_first = tile * CH_TILE + wave;
-    if (f_first < sd.n_c) load_row(f_first, qn, edge_n);
     for (int i = 0; i < P2_FRAMES_PER_WAVE; i++) {
         const uint32_t f = tile * CH_TILE + wave + 4 * i;
         if (f >= sd.n_c) break;  // wave-uniform
-#pragma unroll
-        for (int k = 0; k < P2_CHUNKS; k++) q[k] = qn[k];
-        edge = edge_n;
-        if (i + 1 < P2_FRAMES_PER_WAVE && f + 4 < sd.n_c) load_row(f + 4, qn, edge_n);
-        const float* row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
-        const double ref = 0.1 * (double)frame_max[sd.c_off + f];
-        const float thr0 = ref_floor_f32(ref);
-        const float thr = thr0 > t_lo ? thr0 : t_lo;  // se must exceed ref AND reach the median's neighbourhood
-        const bool strict_lo = t_lo > thr0;           // then thr = t_lo, an INCLUSIVE bound (se >= t_lo implies se > thr0)
-        if (slow_count[wave] + PIP_MAX_PER_FRAME > P2_SLOW_CAP) flush();  // wave-uniform
-        uint32_t n_fast = 0;
-#pragma unroll
-        for (int k = 0; k < P2_CHUNKS; k++) {
-            const float rw = wave_ror1(q[k].w);
-            const float rw_prev = (k > 0) ? wave_ror1(q[k > 0 ? k - 1 : 0].w) : edge;
-            const float left = (lane == 0) ? rw_prev : rw;
-            const float sx = wave_rol1(q[k].x);
-            const float sx_next = (k + 1 < P2_CHUNKS) ? wave_rol1(q[k + 1 < P2_CHUNKS ? k + 1 : k].x) : 0.0f;
-            const float right = (lane == 63) ? sx_next : sx;
-            const float m[6] = {left, q[k].x, q[k].y, q[k].z, q[k].w, right};
-            const int c0 = P2_C0 + 4 * (lane + 64 * k);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int c = c0 + e;
-                const float sb = m[e], se = m[e + 1], sa = m[e + 2];
-                uint32_t kind = 0;
-                if (c >= PIP_LO && c <= PIP_HI && sa <= se && sb < se && (strict_lo ? se >= thr : se > thr)) {
-                    if (se >= t_hi) {
-                        kind = 1;
-                    } else {
-                        const uint32_t b = peak_coarse_bin(sb, se, sa, ref, c);
-                        kind = b > b_hi ? 1u : (b >= b_lo ? 2u : 0u);
-                    }
-                }
-                wave_push(kind != 0, (kind << 12) | (uint32_t)c,
-                          [&](uint32_t pos, uint32_t v) { fast_list[wave][pos] = (uint16_t)v; }, n_fast);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // dense pass: pitch bins in f32 where provable; everything else is queued for the f64 path
-        uint32_t n_slow = slow_count[wave];
-        for (uint32_t j = lane; j < ((n_fast + WAVE - 1) / WAVE) * WAVE; j += WAVE) {  // uniform trip count
+        const uint32_t n_rec = peak_cnt[sd.c_off + f];
+        const uint32_t* __restrict__ recs = peak_rec + (sd.c_off + f) * (size_t)PIP_MAX_PER_FRAME;
+        if (n_slow + PIP_MAX_PER_FRAME > P2_SLOW_CAP) flush();  // wave-uniform
+        for (uint32_t j = lane; j < ((n_rec + WAVE - 1) / WAVE) * WAVE; j += WAVE) {  // uniform trip count
             bool slow = false;
-            int c = 0;
-            if (j < n_fast) {
-                const uint32_t e = fast_list[wave][j];
-                c = (int)(e & 0xFFFu);
-                if ((e >> 12) == 1u) {
-                    const int pb = peak_pitch_bin_f32(row[c - 1], row[c], row[c + 1], c);
-                    if (pb >= 0) atomicAdd(&hist[pb], 1u);
+            uint32_t c = 0;
+            if (j < n_rec) {
+                const uint32_t r = recs[j];
+                const uint32_t b = r >> 18, pbf = (r >> 11) & 0x7Fu;
+                c = r & 0x7FFu;
+                if (b > b_hi) {
+                    if (pbf) atomicAdd(&hist[pbf - 1], 1u);
                     else slow = true;
-                } else {
+                } else if (b >= b_lo) {
                     slow = true;
                 }
             }
-            wave_push(slow, ((uint32_t)i << 16) | (uint32_t)c,
-                      [&](uint32_t pos, uint32_t v) { slow_list[wave][pos] = v; }, n_slow);
+            const uint64_t mask = __ballot(slow);
+            if (mask) {
+                if (slow) slow_list[wave][n_slow + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = ((uint32_t)i << 16) | c;
+                n_slow += (uint32_t)__popcll(mask);
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) slow_count[wave] = n_slow;
-        __builtin_amdgcn_wave_barrier();
     }
+    __builtin_amdgcn_wave_barrier();
     flush();
     __syncthreads();
     if (tid < N_TUNING && hist[tid]) atomicAdd(&hist100[(size_t)s * N_TUNING + tid], hist[tid]);
@@ -722,7 +660,7 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
 void launch_tune_pass2(const Batch& b, const Workspace& w, hipStream_t st) {
     if (b.tiles_ct == 0) return;
     hipLaunchKernelGGL(tune_pass2_kernel, dim3(b.tiles_ct), dim3(256), 0, st, b.songs, b.n_songs, b.pfx_ct, w.spec,
-                       w.frame_max, w.tuning, w.hist100, w.cand_mag, w.cand_pb);
+                       w.frame_max, w.peak_rec, w.peak_cnt, w.tuning, w.hist100, w.cand_mag, w.cand_pb);
 }
 
 // ------------------------------------------------------------------------------------------------
