@@ -186,6 +186,39 @@ __device__ __forceinline__ int peak_pitch_bin_f32(float sb, float se, float sa, 
     return idx < 0 ? 0 : (idx > N_TUNING - 1 ? N_TUNING - 1 : idx);
 }
 
+// coarse magnitude bin AND pitch-residue bin of one established peak from a single evaluation of the parabolic
+// shift (same arithmetic and guard bands as peak_coarse_bin / peak_pitch_bin_f32, which it must agree with bit
+// for bit: tuning pass 2 and the histogram rely on it)
+__device__ __forceinline__ uint32_t peak_classify(float sb, float se, float sa, double ref, int c, int* pitch_bin_out) {
+    const float avg = 0.5f * (sa - sb);
+    const float den = (2.0f * se - sa) - sb;
+    const float shift = avg * __builtin_amdgcn_rcpf(den);
+    const bool normal = se >= 1e-30f;
+    // pitch bin
+    int pb = -1;
+    if (normal && !(den < se * 0.0009765625f)) {
+        float x = 12.0f * (__builtin_amdgcn_logf((float)c + shift) + -3.3528687f);
+        x = x - truncf(x);
+        if (x >= 0.5f) x -= 1.0f;
+        const float q = (x + 0.5f) * 100.0f;
+        const float fl = floorf(q), fr = q - fl;
+        if (!(fr < 0.02f || fr > 0.98f)) {
+            const int idx = (int)fl;
+            pb = idx < 0 ? 0 : (idx > N_TUNING - 1 ? N_TUNING - 1 : idx);
+        }
+    }
+    *pitch_bin_out = pb;
+    // coarse bin
+    const uint32_t bits = __float_as_uint(se + (0.5f * avg) * shift), low = bits & 0x3FFFFu;
+    if (normal && low >= 16u && low <= 0x3FFFFu - 16u) {
+        const uint32_t b = bits >> 18;
+        return b < (uint32_t)H1_BINS ? b : (uint32_t)H1_BINS - 1;
+    }
+    double mag;
+    pip_peak_mag(sb, se, sa, ref, c, &mag);
+    return coarse_bin(mag);
+}
+
 // One 32-bit record per peak, written by the STFT kernel while the frame is still in LDS and consumed by tuning
 // pass 2 (which then never re-scans the spectrogram): exact coarse magnitude bin (13 bits) | pitch-residue bin + 1
 // (7 bits, 0 = the f32 evaluation was not provable, take the f64 path) | centre bin (11 bits).
@@ -465,8 +498,9 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
             for (uint32_t i = t; i < n_peaks; i += 256) {
                 const int c = peak_list[i];
                 const float sb = mags[c - 1], se = mags[c], sa = mags[c + 1];
-                const uint32_t b = peak_coarse_bin(sb, se, sa, ref, c), rel = b - lbase;
-                recs[i] = peak_record(b, peak_pitch_bin_f32(sb, se, sa, c), c);
+                int pb;
+                const uint32_t b = peak_classify(sb, se, sa, ref, c, &pb), rel = b - lbase;
+                recs[i] = peak_record(b, pb, c);
                 if (ABL == 13) { if (rel == 0x7fffffffu) lhist[0] = 1; }
                 else if (rel < (uint32_t)LHIST_BINS) atomicAdd(&lhist[rel], 1u);
                 else atomicAdd(&hist[b], 1u);
