@@ -225,6 +225,34 @@ def test_workspace_chunking(bliss, oracle):
     assert np.array_equal(ref, got) and (status == 0).all()
 
 
+def test_frame_and_tile_boundary_lengths(ctx, oracle):
+    """Song lengths that sit on (and one sample either side of) every framing / tiling boundary of the kernels: the
+    8192-sample minimum, the chroma hop 2205 (ceil(N/2205) frames, last window dropped at exact multiples), 16-frame
+    STFT tiles, 64-frame chroma tiles, the FFT-512 hop 128 / tempo hop 256 / 512-frame tiles, 256-sample energy blocks,
+    1024-sample loudness chunks and the 128-frame beat-tracker step."""
+    lengths = set()
+    for base in (8192, 2205 * 4, 2205 * 16, 2205 * 17, 2205 * 32, 2205 * 64, 2205 * 65, 128 * 512, 128 * 512 + 384, 256 * 255,
+                 256 * 256, 1024 * 40, 256 * 128 * 2, 256 * 128 * 3 + 128, 16 * 4096, 100000):
+        for delta in (-1, 0, 1):
+            if base + delta >= 8192:
+                lengths.add(base + delta)
+    lengths = sorted(lengths)
+    songs = [oracle.white_noise(700 + i, n) for i, n in enumerate(lengths)]
+    got, status = _run(ctx, songs)
+    tuning, n_bpms = ctx.last_tuning(len(songs))
+    assert (status == 0).all()
+    bad_tempo = []
+    for i, (n, x) in enumerate(zip(lengths, songs)):
+        ref = oracle.song_analyze(x)
+        _, otuning = oracle.chroma_desc(x)
+        err = np.abs(got[i] - ref)
+        assert abs(tuning[i] - otuning) < 1e-12, (n, tuning[i], otuning)
+        assert (err[1:] <= _tol(n, 23)[1:]).all(), (n, err)
+        if err[0] > TEMPO_TOL:
+            bad_tempo.append((n, float(got[i][0]), float(ref[0])))
+    assert len(bad_tempo) <= len(lengths) // 10, bad_tempo
+
+
 def test_mixed_duration_corpus_and_cue_slices(bliss, oracle):
     """BASELINE configs[4] in miniature: a ragged corpus of 30 s .. 10 min songs generated in HBM, analysed under a
     workspace limit that forces several chunks; a sample is checked against the oracle and against the same songs
