@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cpu-songs", type=int, default=64)
     ap.add_argument("--no-host-feed", action="store_true", help="skip the PCIe-inclusive host-buffer measurement")
     ap.add_argument("--no-playlist", action="store_true", help="skip the playlist-ordering measurement")
+    ap.add_argument("--ws-limit-gb", type=float, default=0.0, help="workspace limit (chunks the batch); 0 = library default")
     ap.add_argument("--host-feed-songs", type=int, default=256)
     return ap.parse_args()
 
@@ -84,6 +85,8 @@ def main():
 
     n, N, d = args.songs, args.samples, 23
     ctx = bliss.Context(local_rank)
+    if args.ws_limit_gb > 0:
+        ctx.set_workspace_limit(int(args.ws_limit_gb * (1 << 30)))
     offs = np.arange(n, dtype=np.uint64) * np.uint64(N)
     lens = np.full(n, N, np.uint64)
     pcm = torch.empty(n * N, dtype=torch.float32, device="cuda")
