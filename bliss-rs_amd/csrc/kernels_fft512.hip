@@ -75,30 +75,32 @@ struct Tables512 {
     f2 tw512[256];  // W_512^(16 l + e) at [16 e + l]: lane-contiguous (a [16 l + e] layout is a 16-way bank conflict)
 };
 
+// raw samples of one frame: row n1 of lane l = (x[s + 32 n1 + 2l], x[s + 32 n1 + 2l + 1]); samples before the song
+// start are 0 (the reference's zero-initialised sliding buffer); s is a multiple of 128, so pairs never straddle 0
 template <int ABL>
-__device__ __forceinline__ void fft512_frame(__amdgpu_buffer_rsrc_t r_x, long rel_start, int l, f2* tile,
-                                             const Tables512* tabs, FrameMags& out) {
-    f2 v[16];
-    // z[16 n1 + l] = (x[s + 32 n1 + 2l], x[s + 32 n1 + 2l + 1]); samples before the song start are 0
-    // (the reference's zero-initialised sliding buffer); s is a multiple of 128, so pairs never straddle 0
+__device__ __forceinline__ void fft512_load(__amdgpu_buffer_rsrc_t r_x, long rel_start, int l, f2 (&raw)[16]) {
     if (ABL == 3) {
 #pragma unroll
-        for (int n1 = 0; n1 < 16; n1++) v[n1] = mk((float)(l + n1), 1.0f) * tabs->win[16 * n1 + l];
+        for (int n1 = 0; n1 < 16; n1++) raw[n1] = mk((float)(l + n1), 1.0f);
     } else if (rel_start >= 0) {
         const uint32_t xoff = (uint32_t)((rel_start + 2 * l) * 4);
 #pragma unroll
-        for (int n1 = 0; n1 < 16; n1++) {
-            v[n1] = buf_load_f2(r_x, xoff, 128u * n1) * tabs->win[16 * n1 + l];
-        }
+        for (int n1 = 0; n1 < 16; n1++) raw[n1] = buf_load_f2(r_x, xoff, 128u * n1);
     } else {
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1++) {
             const long idx = rel_start + 32 * n1 + 2 * l;
-            f2 xv = mk(0.0f, 0.0f);
-            if (idx >= 0) xv = buf_load_f2(r_x, (uint32_t)(idx * 4), 0);
-            v[n1] = xv * tabs->win[16 * n1 + l];
+            raw[n1] = mk(0.0f, 0.0f);
+            if (idx >= 0) raw[n1] = buf_load_f2(r_x, (uint32_t)(idx * 4), 0);
         }
     }
+}
+
+template <int ABL>
+__device__ __forceinline__ void fft512_compute(const f2 (&raw)[16], int l, f2* tile, const Tables512* tabs, FrameMags& out) {
+    f2 v[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; n1++) v[n1] = raw[n1] * tabs->win[16 * n1 + l];
     radix16(v);  // over n1 -> A[k1] at v[R16(k1)]
 #pragma unroll
     for (int k1 = 1; k1 < 16; k1++) v[R16(k1)] = cmul_pk(v[R16(k1)], tabs->tw256[16 * k1 + l]);  // W_256^(l*k1)
@@ -132,7 +134,7 @@ __device__ __forceinline__ void fft512_frame(__amdgpu_buffer_rsrc_t r_x, long re
 }
 
 template <int ABL>  // ABL != 0: timing ablations (developer aid, BLISSGPU_ABL512), results are wrong
-__global__ __launch_bounds__(256, 4) void fft512_kernel(const float* __restrict__ pcm,
+__global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict__ pcm,
                                                         const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                         const uint32_t* __restrict__ pfx_f,
                                                         const float* __restrict__ hannz,
@@ -170,16 +172,31 @@ __global__ __launch_bounds__(256, 4) void fft512_kernel(const float* __restrict_
     FrameMags cur, prev;
     const bool active = k_begin < (long)sd.n_f;
     // halo: magnitudes of the previous tempo frame (FFT frame k_begin - 1); zeros before the song starts
+    f2 raw[16];
     if (active && k_begin >= 1) {
-        fft512_frame<ABL>(r_x, k_begin * HOP_T - W512 - base, l, tile, tabs, prev);
+        fft512_load<ABL>(r_x, k_begin * HOP_T - W512 - base, l, raw);
+        fft512_compute<ABL>(raw, l, tile, tabs, prev);
     } else {
 #pragma unroll
         for (int e = 0; e < 16; e++) prev.m[e] = 0.0f;
         prev.nyq = 0.0f;
     }
 
+    // Consecutive frames share 384 of their 512 samples: the raw rows stay in registers, every frame shifts them by
+    // four rows and loads only the four new ones -- issued a whole frame ahead, so their latency is off the critical path.
+    if (active) fft512_load<ABL>(r_x, (k_begin + 1) * HOP_T - W512 - base, l, raw);
     for (long k = k_begin; k < k_end; k++) {
-        fft512_frame<ABL>(r_x, (k + 1) * HOP_T - W512 - base, l, tile, tabs, cur);
+        fft512_compute<ABL>(raw, l, tile, tabs, cur);
+        if (k + 1 < k_end) {
+#pragma unroll
+            for (int n1 = 0; n1 < 12; n1++) raw[n1] = raw[n1 + 4];
+            // rows 12..15 of frame k + 1 = samples [(k + 2) * 128 - 128, (k + 2) * 128): never before the song start
+            // (the lane offset addresses row 12 itself: a negative frame start must not wrap the 32-bit lane offset,
+            // the descriptor's range check does not see the scalar offset)
+            const uint32_t xoff = (uint32_t)(((k + 2) * HOP_T - HOP_T - base + 2 * l) * 4);
+#pragma unroll
+            for (int n1 = 12; n1 < 16; n1++) raw[n1] = (ABL == 3) ? mk((float)(l + n1), 1.0f) : buf_load_f2(r_x, xoff, 128u * (n1 - 12));
+        }
 
         if (k & 1) {  // tempo frame j = (k-1)/2 : SpecFlux over bins 0..256
             float f = 0.0f;
