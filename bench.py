@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pairwise", action="store_true")
     ap.add_argument("--pairwise-n", type=int, default=100000)
-    ap.add_argument("--cpu-songs", type=int, default=64)
+    ap.add_argument("--cpu-songs", type=int, default=128, help="songs timed on the CPU oracle (also the parity spot check)")
     ap.add_argument("--no-host-feed", action="store_true", help="skip the PCIe-inclusive host-buffer measurement")
     ap.add_argument("--no-playlist", action="store_true", help="skip the playlist-ordering measurement")
     ap.add_argument("--ws-limit-gb", type=float, default=0.0, help="workspace limit (chunks the batch); 0 = library default")
@@ -46,20 +46,26 @@ def parse():
 
 def cpu_baseline(n_songs, samples, features_version=2):
     """The oracle (C restatement of the reference algorithm, oracle/) on the host cores: the same
-    white-noise songs (bit-identical generator), one song per thread at a time."""
+    white-noise songs (bit-identical generator), one song per thread at a time.  The oracle is memory-bound well
+    before it runs out of cores (on the 2 x 64-core GPU host it peaks around 32 threads), so two thread counts are
+    timed and the better one is reported, with the thread count it used."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
 
-    cores = min(os.cpu_count() or 1, 64, n_songs)
+    ncpu = os.cpu_count() or 1
     pcm = np.concatenate([O.white_noise(i, samples) for i in range(n_songs)])
     offs = np.arange(n_songs, dtype=np.uint64) * np.uint64(samples)
     lens = np.full(n_songs, samples, np.uint64)
-    t0 = time.perf_counter()
-    out, status = O.song_analyze_batch(pcm, offs, lens, features_version, cores)
-    dt = time.perf_counter() - t0
-    return {"value": round(n_songs / dt, 3), "unit": "songs/sec", "cores": cores, "kind": "port",
-            "sample": f"{n_songs} of the same {samples}-sample white-noise songs, oracle/bliss_oracle.c, "
-                      f"{cores} threads, {dt:.2f} s wall"}, out
+    tried = []
+    out = None
+    for cores in sorted({min(ncpu, n_songs, 32), min(ncpu, n_songs, 64)}):
+        t0 = time.perf_counter()
+        out, status = O.song_analyze_batch(pcm, offs, lens, features_version, cores)
+        tried.append((n_songs / (time.perf_counter() - t0), cores))
+    rate, cores = max(tried)
+    return {"value": round(rate, 3), "unit": "songs/sec", "cores": cores, "kind": "port",
+            "sample": f"{n_songs} of the same {samples}-sample white-noise songs, oracle/bliss_oracle.c; "
+                      + ", ".join(f"{c} threads: {r:.1f} songs/s" for r, c in tried) + f" ({ncpu} logical CPUs)"}, out
 
 
 def main():
