@@ -186,6 +186,13 @@ __device__ __forceinline__ int peak_pitch_bin_f32(float sb, float se, float sa, 
     return idx < 0 ? 0 : (idx > N_TUNING - 1 ? N_TUNING - 1 : idx);
 }
 
+// rare exact path of the classifiers, kept out of line so that it does not inflate the register pressure of the hot loop
+__device__ __attribute__((noinline)) uint32_t coarse_bin_exact(float sb, float se, float sa, double ref, int c) {
+    double mag;
+    pip_peak_mag(sb, se, sa, ref, c, &mag);  // always true for c >= PIP_LO (pitch > 0)
+    return coarse_bin(mag);
+}
+
 // coarse magnitude bin AND pitch-residue bin of one established peak from a single evaluation of the parabolic
 // shift (same arithmetic and guard bands as peak_coarse_bin / peak_pitch_bin_f32, which it must agree with bit
 // for bit: tuning pass 2 and the histogram rely on it)
@@ -214,9 +221,7 @@ __device__ __forceinline__ uint32_t peak_classify(float sb, float se, float sa, 
         const uint32_t b = bits >> 18;
         return b < (uint32_t)H1_BINS ? b : (uint32_t)H1_BINS - 1;
     }
-    double mag;
-    pip_peak_mag(sb, se, sa, ref, c, &mag);
-    return coarse_bin(mag);
+    return coarse_bin_exact(sb, se, sa, ref, c);
 }
 
 // One 32-bit record per peak, written by the STFT kernel while the frame is still in LDS and consumed by tuning
