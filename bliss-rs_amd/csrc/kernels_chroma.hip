@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
                                                      const double* __restrict__ bank,
                                                      const TuningState* __restrict__ tuning,
                                                      double* __restrict__ chroma_part) {
-    __shared__ double tile_c[4][16][13];
+    __shared__ double tile_c[4][4][16][13];
     const uint32_t s = find_segment(pfx_cw, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
     const int lane = lane_id(), wave = wave_id();
@@ -894,39 +894,44 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
     for (int st = 0; st + KU <= KSTEPS; st += KU) k_group(st, std::integral_constant<int, KU>{});
     static_assert(KSTEPS % KU == 1, "tail below handles exactly one step");
     k_group(KSTEPS - 1, std::integral_constant<int, 1>{});
-    double feat[10];
-#pragma unroll
-    for (int t = 0; t < 10; t++) feat[t] = 0.0;
+    // Epilogue on all 64 lanes at once: the four C tiles go through LDS so that lane 16 q + i owns frame 16 q + i
+    // (12 chroma values), instead of four passes of the f64 exp / template arithmetic on 16 active lanes each.
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const double4_t cacc = acc[q][0] + acc[q][1];
         // C[row = g + 4r][col = i16]: rows are chroma classes, columns are frames
 #pragma unroll
-        for (int r = 0; r < 3; r++) tile_c[wave][i16][g + 4 * r] = cacc[r];
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 16 && f0 + 16 * q + lane < sd.n_c) {
-            double c[12], sum = 0.0;
+        for (int r = 0; r < 3; r++) tile_c[wave][q][i16][g + 4 * r] = cacc[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    double feat[10];
 #pragma unroll
-            for (int k = 0; k < 12; k++) { c[k] = tile_c[wave][lane][k]; sum += fabs(c[k]); }
-            if (sum < DBL_MIN) sum = 1.0;          // chroma_stft column normalisation (:404-410)
-            double esum = 0.0;
+    for (int t = 0; t < 10; t++) feat[t] = 0.0;
+    if (f0 + lane < sd.n_c) {
+        double c[12], sum = 0.0;
 #pragma unroll
-            for (int k = 0; k < 12; k++) { c[k] = exp((c[k] / sum) * 15.0); esum += fabs(c[k]); }
-            if (esum < 0.0001) esum = 1.0;         // normalize_feature_sequence (:177-188)
+        for (int k = 0; k < 12; k++) { c[k] = tile_c[wave][lane >> 4][lane & 15][k]; sum += fabs(c[k]); }
+        if (sum < DBL_MIN) sum = 1.0;          // chroma_stft column normalisation (:404-410)
+        double esum = 0.0;
 #pragma unroll
-            for (int k = 0; k < 12; k++) c[k] /= esum;
-            feat[0] += interval_feature<0>(c); feat[1] += interval_feature<1>(c);
-            feat[2] += interval_feature<2>(c); feat[3] += interval_feature<3>(c);
-            feat[4] += interval_feature<4>(c); feat[5] += interval_feature<5>(c);
-            feat[6] += interval_feature<6>(c); feat[7] += interval_feature<7>(c);
-            feat[8] += interval_feature<8>(c); feat[9] += interval_feature<9>(c);
-        }
-        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < 12; k++) { c[k] = exp((c[k] / sum) * 15.0); esum += fabs(c[k]); }
+        if (esum < 0.0001) esum = 1.0;         // normalize_feature_sequence (:177-188)
+#pragma unroll
+        for (int k = 0; k < 12; k++) c[k] /= esum;
+        feat[0] = interval_feature<0>(c); feat[1] = interval_feature<1>(c);
+        feat[2] = interval_feature<2>(c); feat[3] = interval_feature<3>(c);
+        feat[4] = interval_feature<4>(c); feat[5] = interval_feature<5>(c);
+        feat[6] = interval_feature<6>(c); feat[7] = interval_feature<7>(c);
+        feat[8] = interval_feature<8>(c); feat[9] = interval_feature<9>(c);
     }
 #pragma unroll
     for (int t = 0; t < 10; t++) {
-        // lanes 16..63 hold zeros; sum the 16 lanes (= 64 frames) of this tile
+        // sum over the 64 frames of this tile in the order of the previous layout: the four frames {i, 16 + i, 32 + i,
+        // 48 + i} first (sequentially, q ascending), then the 16 partial sums by xor-butterfly
         double v = feat[t];
+        const double v1 = __shfl(v, (lane & 15) + 16, WAVE), v2 = __shfl(v, (lane & 15) + 32, WAVE), v3 = __shfl(v, (lane & 15) + 48, WAVE);
+        v = __shfl(v, lane & 15, WAVE);
+        v = ((v + v1) + v2) + v3;
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
         if (lane == 0) chroma_part[(size_t)(pfx_ct[s] + tile64) * 10 + t] = v;
