@@ -58,11 +58,11 @@ def all_gather_features(local_rows, local_indices, n_total: int, group=None, n_l
     idxs = [torch.empty_like(pad_idx) for _ in range(world)]
     dist.all_gather(rows, pad_rows, group=group)
     dist.all_gather(idxs, pad_idx, group=group)
-    full = torch.full((n_total, d), float("nan"), dtype=local_rows.dtype, device=dev)
+    # scatter without a host synchronisation: padding rows (index -1) land in one spare row past the end
+    full = torch.full((n_total + 1, d), float("nan"), dtype=local_rows.dtype, device=dev)
     for r, i in zip(rows, idxs):
-        keep = i >= 0
-        full[i[keep]] = r[keep]
-    return full
+        full.index_copy_(0, torch.where(i < 0, torch.full_like(i, n_total), i), r)
+    return full[:n_total]
 
 
 def row_block(n_rows: int, rank: int, world_size: int):
