@@ -336,6 +336,62 @@ std::vector<T> dedup_playlist(const std::vector<T>& playlist, std::optional<floa
     return dedup_playlist_custom_distance(playlist, distance_threshold, euclidean_builder());
 }
 
+// closest_album_to_group (src/playlist.rs:424-485): the albums of `pool` (songs of `group` removed, songs without an
+// album dropped) ordered by the euclidean distance of their mean analysis to the group's mean analysis, each album
+// ordered by (disc number, track number); `group` itself comes first.
+template <typename T>
+std::vector<T> closest_album_to_group(const std::vector<T>& group, const std::vector<T>& pool_in) {
+    if (group.empty()) throw ProviderError("Mean of empty slice");
+    std::vector<T> pool;
+    for (const auto& s : pool_in) {
+        bool in_group = false;
+        for (const auto& g : group) {
+            const Song &a = as_song(g), &b = as_song(s);
+            if (a.path == b.path && a.analysis == b.analysis && a.album == b.album && a.title == b.title && a.artist == b.artist &&
+                a.track_number == b.track_number && a.disc_number == b.disc_number) { in_group = true; break; }
+        }
+        if (!in_group) pool.push_back(s);
+    }
+    const size_t d = as_song(group[0]).analysis.as_vec().size();
+    auto mean_of = [&](const std::vector<const Song*>& songs) {  // ndarray mean_axis: sequential f32 row sum / n
+        std::vector<float> m(d, 0.0f);
+        for (const Song* s : songs) for (size_t k = 0; k < d; k++) m[k] = m[k] + s->analysis.as_vec()[k];
+        for (size_t k = 0; k < d; k++) m[k] = m[k] / (float)songs.size();
+        return m;
+    };
+    std::vector<std::string> names;
+    std::vector<std::vector<const Song*>> members;
+    for (const auto& s : pool) {
+        const Song& song = as_song(s);
+        if (!song.album) continue;
+        size_t a = 0;
+        while (a < names.size() && names[a] != *song.album) a++;
+        if (a == names.size()) { names.push_back(*song.album); members.emplace_back(); }
+        members[a].push_back(&song);
+    }
+    std::vector<const Song*> gs;
+    for (const auto& g : group) gs.push_back(&as_song(g));
+    const std::vector<float> first = mean_of(gs);
+    std::vector<T> playlist = group;
+    if (!names.empty()) {
+        std::vector<float> means;
+        for (const auto& m : members) { const auto v = mean_of(m); means.insert(means.end(), v.begin(), v.end()); }
+        std::vector<uint32_t> order(names.size());
+        check_ordering(blissgpu_closest_to_songs(first.data(), 1, means.data(), names.size(), (uint32_t)d, BLISSGPU_METRIC_EUCLIDEAN,
+                                                 nullptr, order.data(), nullptr));
+        for (uint32_t a : order) {
+            std::vector<T> al;
+            for (const auto& s : pool) if (as_song(s).album && *as_song(s).album == names[a]) al.push_back(s);
+            std::stable_sort(al.begin(), al.end(), [](const T& x, const T& y) {  // Option<i32>: None < Some
+                const Song &p = as_song(x), &q = as_song(y);
+                return std::make_pair(p.disc_number, p.track_number) < std::make_pair(q.disc_number, q.track_number);
+            });
+            playlist.insert(playlist.end(), al.begin(), al.end());
+        }
+    }
+    return playlist;
+}
+
 // variance_based_weight_matrix (src/playlist.rs:173-221): d x d row-major; host arithmetic in the reference's order
 inline std::vector<float> variance_based_weight_matrix(const std::vector<std::vector<float>>& seeds) {
     if (seeds.size() < 2) throw ProviderError("seeds must contain more than one element");

@@ -101,6 +101,23 @@ int main(int argc, char** argv) {
         CHECK((dedup_playlist_custom_distance(pl, 20.0f, cosine_builder()) == V{&first}));
         CHECK((dedup_playlist(pl, 20.0f) == V{&first}));
         CHECK((dedup_playlist(pl, std::nullopt) == V{&first, &second, &fourth}));
+        // test_closest_to_group (:1112-1260)
+        {
+            auto song = [](const char* path, const char* album, const char* artist, int track, int disc, float value) {
+                Song s3;
+                s3.path = path; s3.artist = artist; s3.track_number = track; s3.disc_number = disc;
+                if (album) s3.album = album;
+                s3.analysis = Analysis(std::vector<float>(23, value), LATEST);
+                return s3;
+            };
+            Song a = song("path-to-first", "Album", "Artist", 1, 1, 0.0f), b = song("path-to-third", "Album", "Another Artist", 2, 1, 10.0f);
+            Song o1 = song("path-to-second-2", "Another Album", "Artist", 1, 1, 0.15f), o2 = song("path-to-second", "Another Album", "Artist", 2, 1, 0.1f);
+            Song p1 = song("path-to-fourth", "Another Album", "Another Artist", 1, 2, 20.0f), p2 = song("path-to-fourth", "Another Album", "Another Artist", 4, 2, 20.0f);
+            Song none = song("path-to-fifth", nullptr, "Third Artist", 0, 0, 40.0f);
+            none.track_number.reset(); none.disc_number.reset();
+            const V got = closest_album_to_group(V{&a, &b}, V{&a, &o2, &p2, &b, &p1, &o1, &none});
+            CHECK((got == V{&a, &b, &o1, &o2, &p1, &p2}));
+        }
         // variance_based_weight_matrix (:1663-1765)
         auto m = variance_based_weight_matrix({{1.0f, 0.0f, 1.0f}, {1.0f, 100.0f, 1.0f}, {1.0f, 200.0f, 1.0f}});
         CHECK(m.size() == 9 && m[0] > m[4] && m[8] > m[4] && m[1] == 0.0f && m[3] == 0.0f);
