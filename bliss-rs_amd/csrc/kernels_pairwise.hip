@@ -119,7 +119,11 @@ __device__ __forceinline__ float unrolled_dot(FX xs, FY ys) {
     return sum;
 }
 
-template <int D, int METRIC, bool DIAG, int ABL = 0>
+// SYM: A and B are the same matrix.  Every metric here is symmetric bit for bit (negating a - b leaves its squares, the
+// quadratic form and the dot products unchanged, and both norm tables come from the same rows), so only the 256 x 256
+// blocks on or above the diagonal are computed; an off-diagonal block is also written transposed, 32 rows at a time
+// through an LDS tile so that the transposed stores are 128-byte runs.
+template <int D, int METRIC, bool DIAG, int ABL = 0, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restrict__ A, uint64_t n,
                                                        const float* __restrict__ B, uint64_t m,
                                                        const float* __restrict__ M, float* __restrict__ out,
@@ -128,7 +132,13 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float sa[PW_ROWS][DP];
     __shared__ float sna[PW_ROWS];
     __shared__ float sm[(METRIC == METRIC_MAHALANOBIS) ? D * D : 1];
+    constexpr int T_ROWS = 32;  // rows staged per transposed write
+    constexpr int T_PITCH = T_ROWS + 1;  // odd pitch: the 8 lanes that assemble one 128-byte run read 8 different banks
+    __shared__ float st[SYM ? PW_COLS : 1][SYM ? T_PITCH : 1];  // staged TRANSPOSED: st[column][row]
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    const uint32_t bi = blockIdx.y / (PW_COLS / PW_ROWS), bj = blockIdx.x;  // 256 x 256 block coordinates
+    if (SYM && bj < bi) return;                                              // mirrored from the block (bj, bi)
+    const bool do_t = SYM && bj > bi;
     const uint64_t i0 = (uint64_t)blockIdx.y * PW_ROWS;
     const uint64_t j0 = (uint64_t)blockIdx.x * PW_COLS + (uint64_t)lane * PW_CPT;
 
@@ -168,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
     for (int k = 0; k < D; k++) wdiag[k] = DIAG ? sm[(k * D + k) % (METRIC == METRIC_MAHALANOBIS ? D * D : 1)] : 0.0f;
 
     const bool vec_ok = ((ld_out & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && (j0 + 3 < m);
-    for (int r = wave; r < (int)rows_here; r += 4) {
+    for (int R0 = 0; R0 < (int)rows_here; R0 += T_ROWS) {
+    for (int r = R0 + wave; r < (int)rows_here && r < R0 + T_ROWS; r += 4) {
         f2 ap[DP / 2];  // the row, two features per register pair
 #pragma unroll
         for (int k4 = 0; k4 < DP / 4; k4++) {  // same address in every lane: LDS broadcast
@@ -246,6 +257,36 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
             for (int c = 0; c < PW_CPT; c++)
                 if (j0 + c < m) orow[c] = res[c];
         }
+        if (do_t) {
+#pragma unroll
+            for (int c = 0; c < PW_CPT; c++) st[PW_CPT * lane + c][r - R0] = res[c];
+        }
+    }
+    if (do_t) {  // workgroup-uniform
+        __syncthreads();
+        // mirrored block: its row bj * 256 + j holds the staged column j, 32 consecutive outputs = one 128-byte run,
+        // assembled by 8 consecutive lanes (16 bytes each) so that every store instruction writes whole lines
+        const int nvalid = ((int)rows_here - R0 < T_ROWS) ? (int)rows_here - R0 : T_ROWS;
+        const bool fast = nvalid == T_ROWS && ((ld_out & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+        const int chunk = tid & 7;
+#pragma unroll
+        for (int p = 0; p < PW_COLS / 32; p++) {
+            const int j = 32 * p + (tid >> 3);
+            const uint64_t jrow = (uint64_t)bj * PW_COLS + (uint64_t)j;
+            if (jrow >= m) continue;
+            float* dst = out + jrow * ld_out + i0 + (uint64_t)R0 + 4 * chunk;
+            if (fast) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 v4;
+                v4.x = st[j][4 * chunk]; v4.y = st[j][4 * chunk + 1]; v4.z = st[j][4 * chunk + 2]; v4.w = st[j][4 * chunk + 3];
+                __builtin_nontemporal_store(v4, reinterpret_cast<f4*>(__builtin_assume_aligned(dst, 16)));
+            } else {
+                for (int q = 0; q < 4; q++)
+                    if (4 * chunk + q < nvalid) dst[q] = st[j][4 * chunk + q];
+            }
+        }
+        __syncthreads();
+    }
     }
 }
 
@@ -297,6 +338,18 @@ static void launch_d(const float* A, uint64_t n, const float* B, uint64_t m, int
                      float* out, uint64_t ld, hipStream_t st) {
     const dim3 grid((uint32_t)((m + PW_COLS - 1) / PW_COLS), (uint32_t)((n + PW_ROWS - 1) / PW_ROWS));
     static const int abl = getenv("BLISSGPU_ABLPW") ? atoi(getenv("BLISSGPU_ABLPW")) : 0;
+    static const bool no_sym = getenv("BLISSGPU_PW_NOSYM") != nullptr;  // developer aid: force the general kernel
+    if (A == B && n == m && abl == 0 && !no_sym) {  // self-distance matrix: upper block triangle + mirrored stores
+        if (metric == METRIC_EUCLIDEAN)
+            hipLaunchKernelGGL((pairwise_kernel<D, METRIC_EUCLIDEAN, false, 0, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
+        else if (metric == METRIC_COSINE)
+            hipLaunchKernelGGL((pairwise_kernel<D, METRIC_COSINE, false, 0, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
+        else if (diag)
+            hipLaunchKernelGGL((pairwise_kernel<D, METRIC_MAHALANOBIS, true, 0, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
+        else
+            hipLaunchKernelGGL((pairwise_kernel<D, METRIC_MAHALANOBIS, false, 0, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
+        return;
+    }
     if (metric == METRIC_EUCLIDEAN && abl == 1)
         hipLaunchKernelGGL((pairwise_kernel<D, METRIC_EUCLIDEAN, false, 1>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
     else if (metric == METRIC_EUCLIDEAN && abl == 2)
