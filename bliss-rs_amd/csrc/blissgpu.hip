@@ -731,16 +731,18 @@ int blissgpu_pairwise(const float* A, uint64_t n, const float* B, uint64_t m, ui
     // rows of the output are produced in slabs of <= 4 GiB so host-sized problems never need n*m device memory
     const uint64_t slab_rows = std::max<uint64_t>(1, std::min<uint64_t>(n, (1ull << 30) / std::max<uint64_t>(m, 1)));
     HIP_TRY(hipMalloc((void**)&dA, n * d * sizeof(float)));
-    hipError_t e = hipMalloc((void**)&dB, m * d * sizeof(float));
+    const bool self = (A == B && n == m);  // self-distance matrix: one device copy, symmetric kernel
+    hipError_t e = self ? hipSuccess : hipMalloc((void**)&dB, m * d * sizeof(float));
+    if (self) dB = dA;
     if (e == hipSuccess) e = hipMalloc((void**)&dO, slab_rows * m * sizeof(float));
     if (e == hipSuccess && metric == BLISSGPU_METRIC_MAHALANOBIS) e = hipMalloc((void**)&dM, (size_t)d * d * sizeof(float));
     if (e != hipSuccess) {
-        (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dO); (void)hipFree(dM);
+        (void)hipFree(dA); if (!self) (void)hipFree(dB); (void)hipFree(dO); (void)hipFree(dM);
         return fail(BLISSGPU_ERR_OOM, "hipMalloc(pairwise)", hipGetErrorString(e));
     }
     rc = BLISSGPU_OK;
     e = hipMemcpyAsync(dA, A, n * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dB, B, m * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && !self) e = hipMemcpyAsync(dB, B, m * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && dM) e = hipMemcpyAsync(dM, M, (size_t)d * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) rc = fail(BLISSGPU_ERR_HIP, "hipMemcpyAsync", hipGetErrorString(e));
     for (uint64_t r0 = 0; !rc && r0 < n; r0 += slab_rows) {
@@ -753,7 +755,7 @@ int blissgpu_pairwise(const float* A, uint64_t n, const float* B, uint64_t m, ui
         }
     }
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dO); (void)hipFree(dM);
+    (void)hipFree(dA); if (!self) (void)hipFree(dB); (void)hipFree(dO); (void)hipFree(dM);
     return rc;
 }
 

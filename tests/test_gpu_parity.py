@@ -388,6 +388,29 @@ def test_pairwise_bit_exact_vs_oracle(bliss, oracle, d):
     assert np.isnan(bliss.playlist.pairwise_distances(Z, B[:4], "cosine")).all()
 
 
+@pytest.mark.parametrize("n", [1, 31, 256, 257, 777, 1000])
+def test_pairwise_self_distance_uses_symmetry_bit_exactly(bliss, ctx, oracle, n):
+    """A == B takes the symmetric kernel (upper block triangle + LDS-staged transposed stores); it must equal the general
+    kernel (A vs a copy of A) and the oracle bit for bit, for every metric, including ragged edge tiles."""
+    import torch
+
+    rng = np.random.default_rng(50 + n)
+    for d in (23, 20):
+        X = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+        A = torch.from_numpy(X).cuda()
+        M = torch.from_numpy(oracle.feature_weights(2 if d == 23 else 1)).cuda()
+        Q = rng.standard_normal((d, d)).astype(np.float32)
+        Mfull = torch.from_numpy((Q @ Q.T / d + np.eye(d, dtype=np.float32)).astype(np.float32)).cuda()
+        for metric, m in (("euclidean", None), ("cosine", None), ("mahalanobis", M), ("mahalanobis", Mfull)):
+            sym = ctx.pairwise(A, A, metric, m).cpu().numpy()
+            gen = ctx.pairwise(A, A.clone(), metric, m).cpu().numpy()
+            assert np.array_equal(sym.view(np.uint32), gen.view(np.uint32)), (n, d, metric)
+            ref = oracle.pairwise(X, X, metric, None if m is None else m.cpu().numpy())
+            assert np.array_equal(sym.view(np.uint32), ref.view(np.uint32)), (n, d, metric)
+        host = bliss.playlist.pairwise_distances(X, X, "euclidean")          # same host pointer => one device copy
+        assert np.array_equal(host.view(np.uint32), oracle.pairwise(X, X, "euclidean").view(np.uint32))
+
+
 def test_pairwise_full_size_properties(ctx, oracle):
     """BASELINE configs[3]: 100 000 x 100 000 euclidean matrix on one GPU (40 GB): zero diagonal, exact
     symmetry and 10^5 random entries against the oracle, all bit-exact."""
