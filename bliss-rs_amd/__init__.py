@@ -20,6 +20,6 @@ from .song import (  # noqa: F401
 from .decoder import Decoder, PreAnalyzedSong, RawPcmDecoder  # noqa: F401
 from . import playlist  # noqa: F401
 from . import library  # noqa: F401
-from .device import Context  # noqa: F401
+from .device import Context, Node  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

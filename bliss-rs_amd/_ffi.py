@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BLISSGPU_LIB: developer aid for A/B timing of two builds of the library on the same box (never a CPU path)
 LIB_PATH = os.environ.get("BLISSGPU_LIB") or os.path.join(_HERE, "libblissgpu.so")
 
-OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_NAN = 0, 1, 2, 3, 4, 5
+OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_NAN, ERR_RCCL = 0, 1, 2, 3, 4, 5, 6
+SAMPLE_F32, SAMPLE_S16 = 0, 1
 SONG_OK, SONG_TOO_SHORT = 0, 1
 METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_MAHALANOBIS = 0, 1, 2
 
@@ -31,9 +32,14 @@ SIGNATURES = {
     "blissgpu_ctx_wait_stream": (C.c_int, [_vp, _vp]),
     "blissgpu_ctx_signal_stream": (C.c_int, [_vp, _vp]),
     "blissgpu_ctx_set_workspace_limit": (C.c_int, [_vp, C.c_uint64]),
+    "blissgpu_ctx_get_workspace_limit": (C.c_uint64, [_vp]),
     "blissgpu_ctx_synchronize": (C.c_int, [_vp]),
     "blissgpu_feature_count": (C.c_uint32, [C.c_uint32]),
     "blissgpu_analyze": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _i32p]),
+    "blissgpu_analyze_interleaved": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, _vp, _i32p]),
+    "blissgpu_analyze_batch_interleaved": (C.c_int, [_vp, C.c_int, C.c_uint32, _u64p, _u64p, C.c_uint32, C.c_uint32, _vp, _i32p]),
+    "blissgpu_pcm_downmix_device": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, C.c_uint64, _vp]),
+    "blissgpu_debug_last_chunks": (C.c_uint64, [_vp]),
     "blissgpu_analyze_batch": (C.c_int, [_vp, _u64p, _u64p, C.c_uint32, C.c_uint32, _vp, _i32p]),
     "blissgpu_analyze_batch_s16": (C.c_int, [_vp, _u64p, _u64p, C.c_uint32, C.c_uint32, _vp, _i32p]),
     "blissgpu_pcm_s16_to_f32_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
@@ -51,6 +57,17 @@ SIGNATURES = {
     "blissgpu_closest_to_songs_device": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp,
                                                    _vp]),
     "blissgpu_song_to_song_device": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp]),
+    "blissgpu_node_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),
+    "blissgpu_node_destroy": (C.c_int, [_vp]),
+    "blissgpu_node_device_count": (C.c_int, [_vp]),
+    "blissgpu_node_ctx": (_vp, [_vp, C.c_int]),
+    "blissgpu_node_shard": (C.c_int, [_vp, _u64p, C.c_uint32, _u32p]),
+    "blissgpu_node_row_block": (None, [_vp, C.c_uint64, C.c_int, _u64p, _u64p]),
+    "blissgpu_node_analyze": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, C.c_uint32, _vp, _i32p]),
+    "blissgpu_node_analyze_device": (C.c_int, [_vp, C.POINTER(_vp), _u64p, _u64p, _u32p, C.c_uint32, C.c_uint32]),
+    "blissgpu_node_features": (_vp, [_vp, C.c_int]),
+    "blissgpu_node_pairwise": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "blissgpu_node_synchronize": (C.c_int, [_vp]),
     "blissgpu_feature_weights": (C.c_int, [C.c_uint32, _vp]),
     "blissgpu_malloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
     "blissgpu_free": (C.c_int, [_vp]),

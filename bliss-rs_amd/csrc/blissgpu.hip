@@ -1,6 +1,6 @@
-// blissgpu.hip -- host side of the C ABI declared in include/blissgpu.h: context, constant tables,
-// workspace carving, batch scheduling (the GPU replacement of the reference's per-song thread pool,
-// src/song/decoder.rs:282-331, and of the five per-descriptor threads, src/song/mod.rs:432-491).
+// blissgpu.hip -- host side of the C ABI declared in include/blissgpu.h: context life cycle, constant tables,
+// feature-vector distances, playlist ordering, device-memory helpers, profiling and debug taps.  The analysis
+// batches (planning, chunk schedule, PCM feed, coalescing front) live in scheduler.hip, the multi-GPU node in node.hip.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -11,109 +11,26 @@
 #include <string>
 #include <vector>
 
-#include "../../include/blissgpu.h"
-#include "internal.hpp"
+#include "ctx.hpp"
 
 using namespace bg;
 
 namespace {
-
 thread_local std::string g_last_error;
-
-int fail(int code, const char* what, const char* detail) {
-    g_last_error = std::string(what) + ": " + (detail ? detail : "");
-    return code;
-}
-
-#define HIP_TRY(expr)                                                              \
-    do {                                                                           \
-        hipError_t e_ = (expr);                                                    \
-        if (e_ != hipSuccess) return fail(BLISSGPU_ERR_HIP, #expr, hipGetErrorString(e_)); \
-    } while (0)
 
 const char* const kKernelNames[K_COUNT] = {
     "pcm_stats_kernel", "fft512_kernel",     "onset_kernel",      "beat_kernel",   "stft8192_kernel", "tune_select_kernel",
     "tune_pass2_kernel", "tune_final_kernel", "chroma_kernel",     "summary_kernel", "assemble_kernel", "pairwise_kernel", "set_distance_kernel", "song_to_song_kernel", "synth_kernel"};
-
-struct EventPair { hipEvent_t a, b; };
-
-template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t cap = 0;  // elements
-    int ensure(size_t n) {
-        if (n <= cap) return BLISSGPU_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = n + n / 8 + 64;
-        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
-        if (e != hipSuccess) { p = nullptr; return fail(BLISSGPU_ERR_OOM, "hipMalloc", hipGetErrorString(e)); }
-        cap = want;
-        return BLISSGPU_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-
 }  // namespace
 
-struct blissgpu_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;      // chroma chain + assembly (the caller-visible stream)
-    hipStream_t aux_stream = nullptr;  // tempo / timbral / loudness chain, joined before the assembly
-    hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_stft = nullptr, ev_join = nullptr, ev_interop = nullptr;
-    bool serial = false;               // BLISSGPU_SERIAL=1: single stream (clean per-kernel timings)
-    int overlap_mode = 0;              // BLISSGPU_OVERLAP=1: start the per-song tails before the FFT-8192 kernel (experiment)
-    uint64_t ws_limit = 96ull << 30;
-    // tables
-    float2 *tw8192 = nullptr, *tw512 = nullptr;
-    float *hann8192 = nullptr, *hannz512 = nullptr, *bt_rwv = nullptr, *bt_dfwv = nullptr;
-    double* chroma_bank = nullptr;
-    DeviceTables tables{};
-    // workspace: one grow-only slab carved per chunk + small descriptor buffers
-    DevBuf<uint8_t> slab;
-    DevBuf<uint8_t> desc;       // SongDesc[] + 4 prefix arrays
-    uint8_t* h_desc = nullptr;  // pinned staging for desc
-    size_t h_desc_cap = 0;
-    DevBuf<int32_t> dbg_tuning;
-    DevBuf<uint32_t> dbg_nbpms;
-    uint32_t dbg_n = 0;
-    // playlist ordering scratch
-    int n_cus = 0;
-    DevBuf<uint32_t> pl_sync, pl_keys;
-    DevBuf<uint8_t> pl_tmp;
-    DevBuf<unsigned long long> pl_slots;
-    Workspace last_ws{};                 // workspace carving of the last chunk (debug taps)
-    std::vector<SongDesc> last_songs;    // its descriptors
-    // profiling
-    bool profiling = false;
-    std::vector<EventPair> events[K_COUNT];
-};
+namespace bg {
+int fail(int code, const char* what, const char* detail) {
+    g_last_error = std::string(what) + ": " + (detail ? detail : "");
+    return code;
+}
+}  // namespace bg
 
 namespace {
-
-struct Prof {  // HIP events around one launch, on the stream the kernel is launched on
-    blissgpu_ctx* c;
-    int k;
-    hipStream_t st;
-    EventPair ev{};
-    bool on;
-    Prof(blissgpu_ctx* ctx, int kernel, hipStream_t stream = nullptr)
-        : c(ctx), k(kernel), st(stream ? stream : ctx->stream), on(ctx->profiling) {
-        if (on) {
-            (void)hipEventCreate(&ev.a);
-            (void)hipEventCreate(&ev.b);
-            (void)hipEventRecord(ev.a, st);
-        }
-    }
-    ~Prof() {
-        if (on) {
-            (void)hipEventRecord(ev.b, st);
-            c->events[k].push_back(ev);
-        }
-    }
-};
 
 template <typename T>
 int upload(T** dst, const std::vector<T>& h) {
@@ -165,217 +82,12 @@ int build_tables(blissgpu_ctx* c) {
     return BLISSGPU_OK;
 }
 
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
-// host-side frame counts; must agree with the reference's framing
-void fill_counts(SongDesc& d) {
-    const uint64_t n = d.n;
-    d.n_t = (uint32_t)((n - W512) / HOP_T + 1);
-    d.n_b = (uint32_t)((n - W512) / HOP_B + 1);
-    d.n_f = std::max(d.n_t, 2u * d.n_b);
-    // src/utils.rs:29-32: rows = (len as f32 / hop as f32).ceil(); the zip with windows() caps it at n/hop + 1
-    const uint32_t rows = (uint32_t)ceilf((float)n / (float)HOP_C);
-    d.n_c = std::min<uint64_t>(rows, n / HOP_C + 1);
-    d.n_e = (uint32_t)((n + 255) / 256);
-    d.n_l = (uint32_t)((n + LOUD_W - 1) / LOUD_W);
-}
-
-size_t song_ws_bytes(const SongDesc& d) {
-    if (!d.ok) return 256;
-    size_t b = 0;
-    b += (size_t)d.n_t * 12 + (size_t)d.n_b * 8 + (size_t)d.n_e * 8;
-    b += (size_t)d.n_c * (CBINS_PAD * 4 + 4);
-    b += (size_t)H1_BINS * 4 + N_TUNING * 4 + sizeof(TuningState) + sizeof(TempoState);
-    b += (size_t)d.n_c * PIP_MAX_PER_FRAME * 9;
-    b += (size_t)d.n_c * (PIP_MAX_PER_FRAME * 4 + 4);
-    b += ((size_t)d.n_c / CH_TILE + 1) * 80;
-    b += ((size_t)d.n_b / BT_STEP + 2) * 8;
-    return b + 4096;
-}
-
-struct Carver {
-    uint8_t* base;
-    size_t off = 0;
-    template <typename T>
-    T* take(size_t n) {
-        off = align_up(off, 256);
-        T* p = reinterpret_cast<T*>(base + off);
-        off += n * sizeof(T);
-        return p;
-    }
-};
-
-int run_chunk(blissgpu_ctx* c, const float* d_pcm, std::vector<SongDesc>& songs, uint32_t features_version,
-              float* d_out) {
-    const uint32_t ns = (uint32_t)songs.size();
-    if (ns == 0) return BLISSGPU_OK;
-    // ---- offsets + tile prefixes ----
-    std::vector<uint32_t> pfx_e(ns + 1, 0), pfx_f(ns + 1, 0), pfx_c(ns + 1, 0), pfx_ct(ns + 1, 0), pfx_cw(ns + 1, 0);
-    uint64_t tot_t = 0, tot_b = 0, tot_c = 0, tot_e = 0, tot_cand = 0;
-    uint32_t max_nb = 0, max_nt = 0, max_runs = 1;
-    for (uint32_t i = 0; i < ns; i++) {
-        SongDesc& d = songs[i];
-        d.t_off = tot_t; d.b_off = tot_b; d.c_off = tot_c; d.e_off = tot_e; d.cand_off = tot_cand;
-        if (d.ok) {
-            tot_t += d.n_t; tot_b += d.n_b; tot_c += d.n_c; tot_e += d.n_e;
-            tot_cand += (uint64_t)d.n_c * PIP_MAX_PER_FRAME;
-            max_nb = std::max(max_nb, d.n_b);
-            max_nt = std::max(max_nt, d.n_t);
-            max_runs = std::max(max_runs, d.n_b / BT_STEP + 1);
-        }
-        pfx_e[i + 1] = pfx_e[i] + (d.ok ? (d.n_e + 15) / 16 : 0);
-        pfx_f[i + 1] = pfx_f[i] + (d.ok ? (d.n_f + F512_TILE - 1) / F512_TILE : 0);
-        pfx_c[i + 1] = pfx_c[i] + (d.ok ? (d.n_c + STFT_TILE - 1) / STFT_TILE : 0);
-        pfx_ct[i + 1] = pfx_ct[i] + (d.ok ? (d.n_c + CH_TILE - 1) / CH_TILE : 0);
-        pfx_cw[i + 1] = pfx_cw[i] + (d.ok ? (d.n_c + 4 * CH_TILE - 1) / (4 * CH_TILE) : 0);
-    }
-    // ---- descriptors to the device (pinned staging, one async copy) ----
-    const size_t desc_bytes = align_up(ns * sizeof(SongDesc), 256) + 5 * align_up((ns + 1) * 4, 256);
-    int rc = c->desc.ensure(desc_bytes);
-    if (rc) return rc;
-    if (desc_bytes > c->h_desc_cap) {
-        if (c->h_desc) (void)hipHostFree(c->h_desc);
-        c->h_desc = nullptr;
-        HIP_TRY(hipHostMalloc((void**)&c->h_desc, desc_bytes + desc_bytes / 4, hipHostMallocDefault));
-        c->h_desc_cap = desc_bytes + desc_bytes / 4;
-    } else {
-        HIP_TRY(hipStreamSynchronize(c->stream));  // the previous chunk may still be reading the staging area
-    }
-    size_t o = 0;
-    const size_t o_songs = o; memcpy(c->h_desc + o, songs.data(), ns * sizeof(SongDesc)); o = align_up(o + ns * sizeof(SongDesc), 256);
-    const size_t o_e = o; memcpy(c->h_desc + o, pfx_e.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
-    const size_t o_f = o; memcpy(c->h_desc + o, pfx_f.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
-    const size_t o_c = o; memcpy(c->h_desc + o, pfx_c.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
-    const size_t o_ct = o; memcpy(c->h_desc + o, pfx_ct.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
-    const size_t o_cw = o; memcpy(c->h_desc + o, pfx_cw.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
-    HIP_TRY(hipMemcpyAsync(c->desc.p, c->h_desc, o, hipMemcpyHostToDevice, c->stream));
-
-    Batch b{};
-    b.pcm = d_pcm;
-    b.songs = reinterpret_cast<const SongDesc*>(c->desc.p + o_songs);
-    b.n_songs = ns;
-    b.pfx_e = reinterpret_cast<const uint32_t*>(c->desc.p + o_e);
-    b.pfx_f = reinterpret_cast<const uint32_t*>(c->desc.p + o_f);
-    b.pfx_c = reinterpret_cast<const uint32_t*>(c->desc.p + o_c);
-    b.pfx_ct = reinterpret_cast<const uint32_t*>(c->desc.p + o_ct);
-    b.pfx_cw = reinterpret_cast<const uint32_t*>(c->desc.p + o_cw);
-    b.tiles_e = pfx_e[ns]; b.tiles_f = pfx_f[ns]; b.tiles_c = pfx_c[ns]; b.tiles_ct = pfx_ct[ns]; b.tiles_cw = pfx_cw[ns];
-    b.total_b = tot_b; b.max_nb = max_nb; b.max_nt = max_nt;
-
-    // ---- carve the workspace ----
-    size_t need = 0;
-    {
-        Carver m{nullptr};
-        m.take<float>(tot_t); m.take<float>(tot_t); m.take<float>(tot_t);
-        m.take<float>(tot_b); m.take<float>(tot_b);
-        m.take<float>(tot_e); m.take<uint32_t>(tot_e);
-        m.take<float>(tot_c * CBINS_PAD + 64); m.take<float>(tot_c);
-        m.take<uint32_t>((size_t)ns * H1_BINS); m.take<uint32_t>((size_t)ns * N_TUNING);
-        m.take<TuningState>(ns);
-        m.take<uint32_t>(tot_cand); m.take<uint32_t>(tot_c);
-        m.take<double>(tot_cand); m.take<uint8_t>(tot_cand);
-        m.take<double>((size_t)b.tiles_ct * 10 + 16);
-        m.take<TempoState>(ns);
-        m.take<float>((size_t)ns * max_runs); m.take<uint32_t>((size_t)ns * max_runs);
-        m.take<float>((size_t)ns * 16);
-        need = m.off + 4096;
-    }
-    if (need > c->slab.cap) HIP_TRY(hipStreamSynchronize(c->stream));
-    rc = c->slab.ensure(need);
-    if (rc) return rc;
-    Carver m{c->slab.p};
-    Workspace w{};
-    w.centroid = m.take<float>(tot_t); w.rolloff = m.take<float>(tot_t); w.flatness = m.take<float>(tot_t);
-    w.flux = m.take<float>(tot_b); w.thresholded = m.take<float>(tot_b);
-    w.e256 = m.take<float>(tot_e); w.zc256 = m.take<uint32_t>(tot_e);
-    w.spec = m.take<float>(tot_c * CBINS_PAD + 64); w.frame_max = m.take<float>(tot_c);
-    w.h1 = m.take<uint32_t>((size_t)ns * H1_BINS); w.hist100 = m.take<uint32_t>((size_t)ns * N_TUNING);
-    w.tuning = m.take<TuningState>(ns);
-    w.peak_rec = m.take<uint32_t>(tot_cand); w.peak_cnt = m.take<uint32_t>(tot_c);
-    w.cand_mag = m.take<double>(tot_cand); w.cand_pb = m.take<uint8_t>(tot_cand);
-    w.chroma_part = m.take<double>((size_t)b.tiles_ct * 10 + 16);
-    w.tempo = m.take<TempoState>(ns);
-    w.run_bpm = m.take<float>((size_t)ns * max_runs); w.run_cnt = m.take<uint32_t>((size_t)ns * max_runs);
-    w.runs_pitch = max_runs;
-    w.summary = m.take<float>((size_t)ns * 16);
-
-    c->last_ws = w;
-    c->last_songs = songs;
-
-    // The reference runs the five descriptors as scoped threads (src/song/mod.rs:432-491).  Here the two
-    // FFT-heavy kernels run back to back on the caller-visible stream; the latency-bound tails of the
-    // tempo / timbral chains (one workgroup per song: sequential beat tracker, sequential summaries)
-    // run beside the chroma chain on the aux stream and are joined before the feature rows are written.
-    hipStream_t st = c->stream, sb = c->serial ? c->stream : c->aux_stream;
-    const bool two = !c->serial;
-    if (two) {
-        HIP_TRY(hipEventRecord(c->ev_start, st));
-        HIP_TRY(hipStreamWaitEvent(sb, c->ev_start, 0));
-    }
-    // aux: the HBM-bound PCM statistics pass (only the aux chain consumes it) runs beside the VALU-bound FFT-512
-    HIP_TRY(hipMemsetAsync(w.h1, 0, (size_t)ns * H1_BINS * 4, st));
-    HIP_TRY(hipMemsetAsync(w.hist100, 0, (size_t)ns * N_TUNING * 4, st));
-    if (two && c->overlap_mode == 2) {
-        // experiment: the whole tempo / timbral chain on the aux stream, concurrent with the chroma chain
-        { Prof p(c, K_PCM_STATS, sb); launch_pcm_stats(b, w, sb); }
-        { Prof p(c, K_FFT512, sb); launch_fft512(b, w, c->tables, sb); }
-        { Prof p(c, K_ONSET, sb); launch_onset(b, w, sb); }
-        { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
-        { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
-        HIP_TRY(hipEventRecord(c->ev_join, sb));
-        { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st); }
-        { Prof p(c, K_TUNE_SELECT); launch_tune_select(b, w, st); }
-        { Prof p(c, K_TUNE_PASS2); launch_tune_pass2(b, w, st); }
-        { Prof p(c, K_TUNE_FINAL); launch_tune_final(b, w, st); }
-        { Prof p(c, K_CHROMA); launch_chroma(b, w, c->tables, st); }
-        HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
-        { Prof p(c, K_FINALIZE); launch_finalize(b, w, features_version, d_out, c->dbg_tuning.p, c->dbg_nbpms.p, st); }
-        HIP_TRY(hipGetLastError());
-        return BLISSGPU_OK;
-    }
-    { Prof p(c, K_PCM_STATS, sb); launch_pcm_stats(b, w, sb); }
-    { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st); }
-    { Prof p(c, K_ONSET); launch_onset(b, w, st); }
-    // aux: the sequential summaries (one lane per song, a few hundred wavefronts in all, memory-latency bound)
-    // start as soon as the FFT-512 series exist and run beside the FFT-8192 kernel
-    if (two) {
-        HIP_TRY(hipEventRecord(c->ev_fork, st));
-        HIP_TRY(hipStreamWaitEvent(sb, c->ev_fork, 0));
-    }
-    { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
-    { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st); }
-    // The beat tracker (one 256-thread workgroup per song) would displace one of the three FFT-8192 workgroups
-    // per CU (168 VGPRs each), so it starts only after that kernel and runs beside the HBM-bound tuning / chroma
-    // kernels, which leave registers free.  BLISSGPU_OVERLAP=1 (experiment): start it beside the FFT-8192 kernel.
-    if (two && c->overlap_mode == 0) {
-        HIP_TRY(hipEventRecord(c->ev_stft, st));
-        HIP_TRY(hipStreamWaitEvent(sb, c->ev_stft, 0));
-    }
-    if (c->overlap_mode != 3) {
-        { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
-        if (two) HIP_TRY(hipEventRecord(c->ev_join, sb));
-    }
-    { Prof p(c, K_TUNE_SELECT); launch_tune_select(b, w, st); }
-    { Prof p(c, K_TUNE_PASS2); launch_tune_pass2(b, w, st); }
-    { Prof p(c, K_TUNE_FINAL); launch_tune_final(b, w, st); }
-    if (c->overlap_mode == 3) {  // experiment: beat tracker beside the chroma contraction only
-        if (two) {
-            HIP_TRY(hipEventRecord(c->ev_stft, st));
-            HIP_TRY(hipStreamWaitEvent(sb, c->ev_stft, 0));
-        }
-        { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
-        if (two) HIP_TRY(hipEventRecord(c->ev_join, sb));
-    }
-    { Prof p(c, K_CHROMA); launch_chroma(b, w, c->tables, st); }
-    if (two) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
-    { Prof p(c, K_FINALIZE); launch_finalize(b, w, features_version, d_out, c->dbg_tuning.p, c->dbg_nbpms.p, st); }
-    HIP_TRY(hipGetLastError());
-    return BLISSGPU_OK;
-}
-
 std::mutex g_default_mu;
 blissgpu_ctx* g_default_ctx = nullptr;
 
+}  // namespace
+
+namespace bg {
 int default_ctx(blissgpu_ctx** out) {
     std::lock_guard<std::mutex> lk(g_default_mu);
     if (!g_default_ctx) {
@@ -385,6 +97,9 @@ int default_ctx(blissgpu_ctx** out) {
     *out = g_default_ctx;
     return BLISSGPU_OK;
 }
+}  // namespace bg
+
+namespace {
 
 int is_diag(const float* M, uint32_t d) {
     for (uint32_t i = 0; i < d; i++)
@@ -395,109 +110,15 @@ int is_diag(const float* M, uint32_t d) {
 
 }  // namespace
 
-// Host-buffer batches (the PCM feed): songs are packed group by group into one of TWO device PCM
-// buffers; the H2D copies of group g + 1 run on the copy stream while group g is analysed, so the transfer -- the
-// real bottleneck of this entry point (a 3-minute song is 15.9 MB, 7.9 MB as s16) -- is never idle.  BYTES = 4:
-// f32 samples copied verbatim; BYTES = 2: s16 samples, widened on the device by pcm_s16_to_f32 (sample / 32768,
-// exactly FFmpeg's s16 -> flt conversion, src/song/decoder/ffmpeg.rs:36-109).
-template <typename SampleT>
-static int analyze_batch_host(const SampleT* pcm, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
-                              uint32_t features_version, float* out, int32_t* status, const char* who) {
-    if (n_songs && (!pcm || !offsets || !lengths || !out)) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
-    const uint32_t d = blissgpu_feature_count(features_version);
-    if (!d) return fail(BLISSGPU_ERR_INVALID, who, "features_version must be 1 or 2");
-    if (n_songs == 0) return BLISSGPU_OK;
-    blissgpu_ctx* c;
-    int rc = default_ctx(&c);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
-    constexpr bool S16 = sizeof(SampleT) == 2;
-    // groups of <= 2 GiB of f32 PCM (~128 three-minute songs): large enough to fill the GPU, small enough to pipeline
-    const uint64_t group_cap = 512ull << 20;  // samples
-    struct Group { uint32_t i0, n; std::vector<uint64_t> doff, dlen; uint64_t total; };
-    std::vector<Group> groups;
-    for (uint32_t i0 = 0; i0 < n_songs;) {
-        Group g{i0, 0, {}, {}, 0};
-        uint32_t i1 = i0;
-        while (i1 < n_songs && (i1 == i0 || g.total + lengths[i1] <= group_cap)) {
-            g.doff.push_back(g.total);
-            g.dlen.push_back(lengths[i1]);
-            g.total += (lengths[i1] + 63) / 64 * 64;
-            i1++;
-        }
-        g.n = i1 - i0;
-        groups.push_back(std::move(g));
-        i0 = i1;
-    }
-    uint64_t max_total = 64, max_n = 1;
-    for (const auto& g : groups) { max_total = std::max(max_total, g.total); max_n = std::max<uint64_t>(max_n, g.n); }
-    const int nbuf = groups.size() > 1 ? 2 : 1;
-    float* d_pcm[2] = {nullptr, nullptr};
-    SampleT* d_raw[2] = {nullptr, nullptr};  // s16 staging (S16 only)
-    float* d_out[2] = {nullptr, nullptr};
-    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-    hipStream_t copy_stream = nullptr;
-    auto cleanup = [&]() {
-        (void)hipStreamSynchronize(c->stream);
-        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
-        for (int b = 0; b < 2; b++) {
-            (void)hipFree(d_pcm[b]); (void)hipFree(d_raw[b]); (void)hipFree(d_out[b]);
-            if (ev_copied[b]) (void)hipEventDestroy(ev_copied[b]);
-            if (ev_done[b]) (void)hipEventDestroy(ev_done[b]);
-        }
-    };
-    hipError_t e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
-    for (int b = 0; b < nbuf && e == hipSuccess; b++) {
-        e = hipMalloc((void**)&d_pcm[b], max_total * sizeof(float));
-        if (e == hipSuccess && S16) e = hipMalloc((void**)&d_raw[b], max_total * sizeof(SampleT));
-        if (e == hipSuccess) e = hipMalloc((void**)&d_out[b], max_n * d * sizeof(float));
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_copied[b], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_done[b], hipEventDisableTiming);
-    }
-    if (e != hipSuccess) { cleanup(); return fail(BLISSGPU_ERR_OOM, "hipMalloc(host batch)", hipGetErrorString(e)); }
-
-    auto upload = [&](size_t gi) -> hipError_t {  // H2D of group gi into buffer gi % nbuf, on the copy stream
-        const Group& g = groups[gi];
-        const int b = (int)(gi % nbuf);
-        hipError_t ee = hipSuccess;
-        if (gi >= (size_t)nbuf) ee = hipStreamWaitEvent(copy_stream, ev_done[b], 0);  // buffer b is free again
-        for (uint32_t k = 0; k < g.n && ee == hipSuccess; k++)
-            if (g.dlen[k]) {
-                void* dst = S16 ? (void*)(d_raw[b] + g.doff[k]) : (void*)(d_pcm[b] + g.doff[k]);
-                ee = hipMemcpyAsync(dst, pcm + offsets[g.i0 + k], g.dlen[k] * sizeof(SampleT), hipMemcpyHostToDevice, copy_stream);
-            }
-        if (ee == hipSuccess) ee = hipEventRecord(ev_copied[b], copy_stream);
-        return ee;
-    };
-
-    rc = BLISSGPU_OK;
-    e = upload(0);
-    for (size_t gi = 0; gi < groups.size() && e == hipSuccess && !rc; gi++) {
-        const Group& g = groups[gi];
-        const int b = (int)(gi % nbuf);
-        e = hipStreamWaitEvent(c->stream, ev_copied[b], 0);
-        if (e != hipSuccess) break;
-        if (S16) launch_pcm_s16_to_f32(reinterpret_cast<const int16_t*>(d_raw[b]), d_pcm[b], g.total, c->stream);
-        rc = blissgpu_analyze_batch_device(c, d_pcm[b], g.doff.data(), g.dlen.data(), g.n, features_version, d_out[b], nullptr);
-        if (rc) break;
-        e = hipMemcpyAsync(out + (size_t)g.i0 * d, d_out[b], (size_t)g.n * d * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipEventRecord(ev_done[b], c->stream);
-        // the next group's transfer overlaps this group's kernels (pageable sources block the host here, not the GPU)
-        if (e == hipSuccess && gi + 1 < groups.size()) e = upload(gi + 1);
-        if (status)
-            for (uint32_t k = 0; k < g.n; k++)
-                status[g.i0 + k] = g.dlen[k] >= (uint64_t)MIN_SAMPLES ? BLISSGPU_SONG_OK : BLISSGPU_SONG_TOO_SHORT;
-    }
-    if (e == hipSuccess && !rc) e = hipStreamSynchronize(c->stream);
-    cleanup();
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(BLISSGPU_ERR_HIP, who, hipGetErrorString(e));
-    return BLISSGPU_OK;
-}
+// Locks the context for the duration of one entry point and selects its device.
+#define CTX_ENTER(c, who)                                                     \
+    if (!(c)) return fail(BLISSGPU_ERR_INVALID, who, "ctx is NULL");          \
+    std::lock_guard<std::recursive_mutex> ctx_lock_((c)->mu);                 \
+    HIP_TRY(hipSetDevice((c)->device))
 
 extern "C" {
 
-const char* blissgpu_version(void) { return "blissgpu 0.1.0 (gfx950)"; }
+const char* blissgpu_version(void) { return "blissgpu 0.2.0 (gfx950)"; }
 const char* blissgpu_last_error(void) { return g_last_error.c_str(); }
 
 const char* blissgpu_strerror(int code) {
@@ -508,6 +129,7 @@ const char* blissgpu_strerror(int code) {
         case BLISSGPU_ERR_HIP: return "HIP runtime error";
         case BLISSGPU_ERR_NAN: return "a distance is NaN";
         case BLISSGPU_ERR_OOM: return "out of device memory";
+        case BLISSGPU_ERR_RCCL: return "RCCL error";
         default: return "unknown error";
     }
 }
@@ -528,14 +150,20 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
     if (se != hipSuccess) { delete c; return fail(BLISSGPU_ERR_HIP, "hipStreamCreate", hipGetErrorString(se)); }
     c->stream = c->own_stream;
     se = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
-    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming);
-    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_stft, hipEventDisableTiming);
-    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_interop, hipEventDisableTiming);
+    if (se == hipSuccess) se = hipHostMalloc((void**)&c->h_scalar, 64, hipHostMallocDefault);
     if (se != hipSuccess) { blissgpu_ctx_destroy(c); return fail(BLISSGPU_ERR_HIP, "aux stream/events", hipGetErrorString(se)); }
     if (const char* e = getenv("BLISSGPU_SERIAL")) c->serial = (e[0] == '1');
-    if (const char* e = getenv("BLISSGPU_OVERLAP")) c->overlap_mode = atoi(e);
+    // developer / test aid: slots per chroma frame of the tuning-candidate pool (0 forces the re-scan path of tune_final_kernel)
+    if (const char* e = getenv("BLISSGPU_CAND_BUDGET")) c->cand_budget = (uint32_t)std::max(0, atoi(e));
+    // Scratch limit per chunk slot: a third of what is free now, at most 64 GiB (1024 three-minute songs need ~37 GB).  A
+    // batch that needs more runs as several chunks; a chunk that still does not fit (the caller allocated in the meantime)
+    // is halved until it does.
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
+        c->ws_limit = std::max<uint64_t>(256ull << 20, std::min<uint64_t>(64ull << 30, free_b / 3));
+    else
+        c->ws_limit = 16ull << 30;
     int rc = build_tables(c);
     if (rc) { blissgpu_ctx_destroy(c); return rc; }
     *out = c;
@@ -544,27 +172,30 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
 
 int blissgpu_ctx_destroy(blissgpu_ctx* c) {
     if (!c) return BLISSGPU_OK;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    for (auto& v : c->events)
-        for (auto& ev : v) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    (void)hipFree(c->tw8192); (void)hipFree(c->tw512); (void)hipFree(c->hann8192); (void)hipFree(c->hannz512);
-    (void)hipFree(c->bt_rwv); (void)hipFree(c->bt_dfwv); (void)hipFree(c->chroma_bank);
-    c->slab.release(); c->desc.release(); c->dbg_tuning.release(); c->dbg_nbpms.release();
-    if (c->h_desc) (void)hipHostFree(c->h_desc);
-    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
-    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_stft) (void)hipEventDestroy(c->ev_stft);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->ev_interop) (void)hipEventDestroy(c->ev_interop);
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    {
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+        for (auto& v : c->events)
+            for (auto& ev : v) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+        (void)hipFree(c->tw8192); (void)hipFree(c->tw512); (void)hipFree(c->hann8192); (void)hipFree(c->hannz512);
+        (void)hipFree(c->bt_rwv); (void)hipFree(c->bt_dfwv); (void)hipFree(c->chroma_bank);
+        scheduler_release(c);
+        c->dbg_tuning.release(); c->dbg_nbpms.release();
+        c->pl_sync.release(); c->pl_keys.release(); c->pl_tmp.release(); c->pl_slots.release();
+        c->st_a.release(); c->st_b.release(); c->st_m.release(); c->st_dist.release(); c->st_out.release();
+        if (c->h_scalar) (void)hipHostFree(c->h_scalar);
+        if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+        if (c->ev_interop) (void)hipEventDestroy(c->ev_interop);
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    }
     delete c;
     return BLISSGPU_OK;
 }
 
 int blissgpu_ctx_set_stream(blissgpu_ctx* c, void* s) {
-    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_set_stream", "ctx is NULL");
+    CTX_ENTER(c, "blissgpu_ctx_set_stream");
     (void)hipStreamSynchronize(c->stream);
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return BLISSGPU_OK;
@@ -574,17 +205,15 @@ void* blissgpu_ctx_get_stream(blissgpu_ctx* c) { return c ? (void*)c->stream : n
 // Stream interop for hosts that keep their own streams (e.g. torch's current stream, NULL = the legacy default
 // stream): order the context's stream after / before work queued on another stream without a host synchronisation.
 int blissgpu_ctx_wait_stream(blissgpu_ctx* c, void* producer_stream) {
-    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_wait_stream", "ctx is NULL");
+    CTX_ENTER(c, "blissgpu_ctx_wait_stream");
     if ((hipStream_t)producer_stream == c->stream) return BLISSGPU_OK;
-    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord(c->ev_interop, (hipStream_t)producer_stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_interop, 0));
     return BLISSGPU_OK;
 }
 int blissgpu_ctx_signal_stream(blissgpu_ctx* c, void* consumer_stream) {
-    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_signal_stream", "ctx is NULL");
+    CTX_ENTER(c, "blissgpu_ctx_signal_stream");
     if ((hipStream_t)consumer_stream == c->stream) return BLISSGPU_OK;
-    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord(c->ev_interop, c->stream));
     HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, c->ev_interop, 0));
     return BLISSGPU_OK;
@@ -592,73 +221,18 @@ int blissgpu_ctx_signal_stream(blissgpu_ctx* c, void* consumer_stream) {
 
 int blissgpu_ctx_set_workspace_limit(blissgpu_ctx* c, uint64_t bytes) {
     if (!c || bytes < (64ull << 20)) return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_set_workspace_limit", "limit < 64 MiB");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     c->ws_limit = bytes;
     return BLISSGPU_OK;
 }
+uint64_t blissgpu_ctx_get_workspace_limit(blissgpu_ctx* c) { return c ? c->ws_limit : 0; }
 
 int blissgpu_ctx_synchronize(blissgpu_ctx* c) {
     if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_synchronize", "ctx is NULL");
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return BLISSGPU_OK;
-}
-
-int blissgpu_analyze_batch_device(blissgpu_ctx* c, const float* d_pcm, const uint64_t* offsets, const uint64_t* lengths,
-                                  uint32_t n_songs, uint32_t features_version, float* d_out, int32_t* d_status) {
-    if (!c || (n_songs && (!d_pcm || !offsets || !lengths || !d_out)))
-        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_batch_device", "NULL argument");
-    if (features_version != BLISSGPU_FEATURES_V1 && features_version != BLISSGPU_FEATURES_V2)
-        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_batch_device", "features_version must be 1 or 2");
-    if (n_songs == 0) return BLISSGPU_OK;
+    hipStream_t st;
+    { std::lock_guard<std::recursive_mutex> lk(c->mu); st = c->stream; }
     HIP_TRY(hipSetDevice(c->device));
-    int rc;
-    if ((rc = c->dbg_tuning.ensure(n_songs))) return rc;
-    if ((rc = c->dbg_nbpms.ensure(n_songs))) return rc;
-    c->dbg_n = n_songs;
-
-    std::vector<int32_t> status(n_songs);
-    std::vector<SongDesc> chunk;
-    size_t chunk_bytes = 0;
-    for (uint32_t i = 0; i < n_songs; i++) {
-        SongDesc d{};
-        d.pcm_off = offsets[i];
-        d.n = lengths[i];
-        d.row = i;
-        d.ok = lengths[i] >= (uint64_t)MIN_SAMPLES;  // src/song/mod.rs:417-430
-        status[i] = d.ok ? BLISSGPU_SONG_OK : BLISSGPU_SONG_TOO_SHORT;
-        if (d.ok) fill_counts(d);
-        const size_t sb = song_ws_bytes(d);
-        if (!chunk.empty() && chunk_bytes + sb > c->ws_limit) {
-            if ((rc = run_chunk(c, d_pcm, chunk, features_version, d_out))) return rc;
-            chunk.clear();
-            chunk_bytes = 0;
-        }
-        chunk.push_back(d);
-        chunk_bytes += sb;
-    }
-    if ((rc = run_chunk(c, d_pcm, chunk, features_version, d_out))) return rc;
-    if (d_status) {
-        // pageable source: HIP stages it before returning
-        HIP_TRY(hipMemcpyAsync(d_status, status.data(), n_songs * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    return BLISSGPU_OK;
-}
-
-int blissgpu_analyze_batch(const float* pcm, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
-                           uint32_t features_version, float* out, int32_t* status) {
-    return analyze_batch_host<float>(pcm, offsets, lengths, n_songs, features_version, out, status, "blissgpu_analyze_batch");
-}
-
-int blissgpu_analyze_batch_s16(const int16_t* pcm, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
-                               uint32_t features_version, float* out, int32_t* status) {
-    return analyze_batch_host<int16_t>(pcm, offsets, lengths, n_songs, features_version, out, status, "blissgpu_analyze_batch_s16");
-}
-
-int blissgpu_pcm_s16_to_f32_device(blissgpu_ctx* c, const int16_t* d_in, uint64_t n, float* d_out) {
-    if (!c || (n && (!d_in || !d_out))) return fail(BLISSGPU_ERR_INVALID, "blissgpu_pcm_s16_to_f32_device", "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
-    launch_pcm_s16_to_f32(d_in, d_out, n, c->stream);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));  // not under the lock: other threads may keep enqueueing
     return BLISSGPU_OK;
 }
 
@@ -669,15 +243,6 @@ int blissgpu_host_alloc(void** p, uint64_t bytes) {
     return BLISSGPU_OK;
 }
 int blissgpu_host_free(void* p) { HIP_TRY(hipHostFree(p)); return BLISSGPU_OK; }
-
-int blissgpu_analyze(const float* pcm, uint64_t len, uint32_t features_version, float* out, int32_t* status) {
-    const uint64_t off = 0;
-    int32_t st = 0;
-    const float dummy = 0.0f;
-    int rc = blissgpu_analyze_batch(pcm ? pcm : &dummy, &off, &len, 1, features_version, out, &st);
-    if (status) *status = st;
-    return rc;
-}
 
 int blissgpu_feature_weights(uint32_t features_version, float* M) {
     const uint32_t d = blissgpu_feature_count(features_version);
@@ -701,13 +266,17 @@ int blissgpu_pairwise_device(blissgpu_ctx* c, const float* d_A, uint64_t n, cons
         return fail(BLISSGPU_ERR_INVALID, "blissgpu_pairwise_device", "bad d / metric / ld_out");
     if (metric == BLISSGPU_METRIC_MAHALANOBIS && !d_M)
         return fail(BLISSGPU_ERR_INVALID, "blissgpu_pairwise_device", "mahalanobis needs M");
-    HIP_TRY(hipSetDevice(c->device));
+    CTX_ENTER(c, "blissgpu_pairwise_device");
     int diag = 0;
     if (metric == BLISSGPU_METRIC_MAHALANOBIS) {
-        std::vector<float> hM((size_t)d * d);
-        HIP_TRY(hipMemcpyAsync(hM.data(), d_M, hM.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        diag = is_diag(hM.data(), d);
+        if (d_M == c->st_m.p && c->m_cache.size() == (size_t)d * d) {  // staged by a host form: the host copy is at hand
+            diag = is_diag(c->m_cache.data(), d);
+        } else {
+            std::vector<float> hM((size_t)d * d);
+            HIP_TRY(hipMemcpyAsync(hM.data(), d_M, hM.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            diag = is_diag(hM.data(), d);
+        }
     }
     {
         Prof p(c, K_PAIRWISE);
@@ -716,6 +285,32 @@ int blissgpu_pairwise_device(blissgpu_ctx* c, const float* d_A, uint64_t n, cons
     HIP_TRY(hipGetLastError());
     return BLISSGPU_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+// Stage the d x d matrix of a host-pointer call in the context (uploaded only when it differs from the one staged last:
+// a library is ordered with the same weights over and over).  Returns the device pointer through *d_M (NULL if none).
+int stage_matrix(blissgpu_ctx* c, const float* M, uint32_t d, int metric, const float** d_M) {
+    *d_M = nullptr;
+    if (metric != BLISSGPU_METRIC_MAHALANOBIS) return BLISSGPU_OK;
+    const size_t n = (size_t)d * d;
+    int rc = c->st_m.ensure(4096);  // 64 x 64: never regrown, so the pointer identifies "staged by us"
+    if (rc) return rc;
+    if (c->m_cache.size() != n || memcmp(c->m_cache.data(), M, n * sizeof(float)) != 0) {
+        c->m_cache.assign(M, M + n);
+        // the source is the context's own copy: the caller's buffer may go away as soon as the call returns
+        HIP_TRY(hipMemcpyAsync(c->st_m.p, c->m_cache.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    *d_M = c->st_m.p;
+    return BLISSGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int blissgpu_pairwise(const float* A, uint64_t n, const float* B, uint64_t m, uint32_t d, int metric, const float* M,
                       float* out) {
@@ -726,27 +321,22 @@ int blissgpu_pairwise(const float* A, uint64_t n, const float* B, uint64_t m, ui
     blissgpu_ctx* c;
     int rc = default_ctx(&c);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
-    float *dA = nullptr, *dB = nullptr, *dM = nullptr, *dO = nullptr;
+    CTX_ENTER(c, "blissgpu_pairwise");
     // rows of the output are produced in slabs of <= 4 GiB so host-sized problems never need n*m device memory
     const uint64_t slab_rows = std::max<uint64_t>(1, std::min<uint64_t>(n, (1ull << 30) / std::max<uint64_t>(m, 1)));
-    HIP_TRY(hipMalloc((void**)&dA, n * d * sizeof(float)));
     const bool self = (A == B && n == m);  // self-distance matrix: one device copy, symmetric kernel
-    hipError_t e = self ? hipSuccess : hipMalloc((void**)&dB, m * d * sizeof(float));
-    if (self) dB = dA;
-    if (e == hipSuccess) e = hipMalloc((void**)&dO, slab_rows * m * sizeof(float));
-    if (e == hipSuccess && metric == BLISSGPU_METRIC_MAHALANOBIS) e = hipMalloc((void**)&dM, (size_t)d * d * sizeof(float));
-    if (e != hipSuccess) {
-        (void)hipFree(dA); if (!self) (void)hipFree(dB); (void)hipFree(dO); (void)hipFree(dM);
-        return fail(BLISSGPU_ERR_OOM, "hipMalloc(pairwise)", hipGetErrorString(e));
-    }
-    rc = BLISSGPU_OK;
-    e = hipMemcpyAsync(dA, A, n * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    const float* dM = nullptr;
+    if ((rc = c->st_a.ensure(n * d))) return rc;
+    if (!self && (rc = c->st_b.ensure(m * d))) return rc;
+    if ((rc = c->st_out.ensure(slab_rows * m * sizeof(float)))) return rc;
+    if ((rc = stage_matrix(c, M, d, metric, &dM))) return rc;
+    float *dA = c->st_a.p, *dB = self ? c->st_a.p : c->st_b.p, *dO = reinterpret_cast<float*>(c->st_out.p);
+    hipError_t e = hipMemcpyAsync(dA, A, n * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && !self) e = hipMemcpyAsync(dB, B, m * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && dM) e = hipMemcpyAsync(dM, M, (size_t)d * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) rc = fail(BLISSGPU_ERR_HIP, "hipMemcpyAsync", hipGetErrorString(e));
     for (uint64_t r0 = 0; !rc && r0 < n; r0 += slab_rows) {
         const uint64_t rows = std::min(slab_rows, n - r0);
+        // a row slab of a self-distance matrix is not square: only the full matrix takes the symmetric kernel
         rc = blissgpu_pairwise_device(c, dA + r0 * d, rows, dB, m, d, metric, dM, dO, m);
         if (!rc) {
             e = hipMemcpyAsync(out + r0 * m, dO, rows * m * sizeof(float), hipMemcpyDeviceToHost, c->stream);
@@ -755,21 +345,37 @@ int blissgpu_pairwise(const float* A, uint64_t n, const float* B, uint64_t m, ui
         }
     }
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(dA); if (!self) (void)hipFree(dB); (void)hipFree(dO); (void)hipFree(dM);
     return rc;
 }
 
+// One pair: both vectors travel in the kernel arguments and the result lands in a page-locked word, so the call is
+// one launch + one stream synchronisation -- no allocation, no staging copy (Song::distance, src/song/mod.rs:519-521).
 int blissgpu_distance(const float* a, const float* b, uint32_t d, int metric, const float* M, float* out) {
-    return blissgpu_pairwise(a, 1, b, 1, d, metric, M, out);
+    if (!a || !b || !out) return fail(BLISSGPU_ERR_INVALID, "blissgpu_distance", "NULL argument");
+    if (d == 0 || d > 64 || metric < 0 || metric > 2) return fail(BLISSGPU_ERR_INVALID, "blissgpu_distance", "bad d / metric");
+    if (metric == BLISSGPU_METRIC_MAHALANOBIS && !M) return fail(BLISSGPU_ERR_INVALID, "blissgpu_distance", "mahalanobis needs M");
+    blissgpu_ctx* c;
+    int rc = default_ctx(&c);
+    if (rc) return rc;
+    CTX_ENTER(c, "blissgpu_distance");
+    const float* dM = nullptr;
+    if ((rc = stage_matrix(c, M, d, metric, &dM))) return rc;
+    launch_pair_distance(a, b, d, metric, dM, c->h_scalar, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = *c->h_scalar;
+    return BLISSGPU_OK;
 }
 
 // ---- playlist ordering (src/playlist.rs:24-59, 256-326) ----
 static int playlist_args_ok(const char* who, const void* a, const void* b, const void* o, uint32_t n_seeds, uint64_t n,
                             uint32_t d, int metric, const float* M) {
-    if (!a || !b || !o) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
+    // An EMPTY seed set is legal: FunctionDistanceMetric::distance sums over no vectors, i.e. 0.0 for every candidate
+    // (src/playlist.rs:52-58) -- closest_to_songs then keeps the candidates' order (stable sort) and song_to_song
+    // starts from the first candidate.
+    if ((n_seeds && !a) || (n && !b) || !o) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
     if (d == 0 || d > 64 || metric < 0 || metric > 2) return fail(BLISSGPU_ERR_INVALID, who, "bad d / metric");
     if (metric == BLISSGPU_METRIC_MAHALANOBIS && !M) return fail(BLISSGPU_ERR_INVALID, who, "mahalanobis needs M");
-    if (n_seeds == 0) return fail(BLISSGPU_ERR_INVALID, who, "empty seed set");
     if (n > 0xFFFFFFFFull) return fail(BLISSGPU_ERR_INVALID, who, "more than 2^32 - 1 candidates");
     return BLISSGPU_OK;
 }
@@ -789,7 +395,7 @@ int blissgpu_set_distance_device(blissgpu_ctx* c, const float* d_seeds, uint32_t
     int rc = playlist_args_ok("blissgpu_set_distance_device", d_seeds, d_cand, d_out, n_seeds, n, d, metric, d_M);
     if (rc) return rc;
     if (n == 0) return BLISSGPU_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    CTX_ENTER(c, "blissgpu_set_distance_device");
     rc = c->pl_sync.ensure(4);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->pl_sync.p, 0, 4 * sizeof(uint32_t), c->stream));
@@ -807,7 +413,7 @@ int blissgpu_closest_to_songs_device(blissgpu_ctx* c, const float* d_seeds, uint
     int rc = playlist_args_ok("blissgpu_closest_to_songs_device", d_seeds, d_cand, d_order, n_seeds, n, d, metric, d_M);
     if (rc) return rc;
     if (n == 0) return BLISSGPU_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    CTX_ENTER(c, "blissgpu_closest_to_songs_device");
     const uint32_t n32 = (uint32_t)n;
     size_t tmp_bytes = 0;
     HIP_TRY(sort_pairs_u32(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, n32, c->stream));
@@ -832,7 +438,7 @@ int blissgpu_song_to_song_device(blissgpu_ctx* c, const float* d_seeds, uint32_t
     int rc = playlist_args_ok("blissgpu_song_to_song_device", d_seeds, d_cand, d_order, n_seeds, n, d, metric, d_M);
     if (rc) return rc;
     if (n == 0) return BLISSGPU_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    CTX_ENTER(c, "blissgpu_song_to_song_device");
     // one workgroup per 256 candidates up to one per CU (all workgroups must be co-resident: the kernel spins on
     // a grid barrier); each thread then owns ceil(n / (256 G)) <= 64 candidates
     // four candidates per thread (register-resident) is the sweet spot: fewer workgroups make the grid barrier and the
@@ -854,28 +460,31 @@ int blissgpu_song_to_song_device(blissgpu_ctx* c, const float* d_seeds, uint32_t
     return nan_check(c, c->pl_sync.p + 1, "blissgpu_song_to_song_device");
 }
 
-// host-pointer wrappers: stage seeds / candidates / M, run the device form, copy the result back
+}  // extern "C"
+
+// host-pointer wrappers: stage seeds / candidates / M in the context's buffers, run the device form, copy the result back
 namespace {
 struct PlStage {
-    float *seeds = nullptr, *cand = nullptr, *M = nullptr;
+    blissgpu_ctx* c;
+    float *seeds = nullptr, *cand = nullptr, *dist = nullptr;
+    const float* M = nullptr;
     void* out = nullptr;
-    float* dist = nullptr;
-    ~PlStage() { (void)hipFree(seeds); (void)hipFree(cand); (void)hipFree(M); (void)hipFree(out); (void)hipFree(dist); }
-    int up(blissgpu_ctx* c, const float* h_seeds, uint32_t n_seeds, const float* h_cand, uint64_t n, uint32_t d, int metric,
-           const float* h_M, size_t out_bytes, bool want_dist) {
-        hipError_t e = hipMalloc((void**)&seeds, (size_t)n_seeds * d * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&cand, std::max<size_t>(1, n * d) * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(&out, std::max<size_t>(4, out_bytes));
-        if (e == hipSuccess && want_dist) e = hipMalloc((void**)&dist, std::max<size_t>(1, n) * sizeof(float));
-        if (e == hipSuccess && metric == BLISSGPU_METRIC_MAHALANOBIS) e = hipMalloc((void**)&M, (size_t)d * d * sizeof(float));
-        if (e != hipSuccess) return fail(BLISSGPU_ERR_OOM, "hipMalloc(playlist)", hipGetErrorString(e));
-        e = hipMemcpyAsync(seeds, h_seeds, (size_t)n_seeds * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    int up(const float* h_seeds, uint32_t n_seeds, const float* h_cand, uint64_t n, uint32_t d, int metric, const float* h_M,
+           size_t out_bytes, bool want_dist) {
+        int rc = c->st_a.ensure(std::max<size_t>(1, (size_t)n_seeds * d));
+        if (!rc) rc = c->st_b.ensure(std::max<size_t>(1, n * d));
+        if (!rc) rc = c->st_out.ensure(std::max<size_t>(4, out_bytes));
+        if (!rc && want_dist) rc = c->st_dist.ensure(std::max<size_t>(1, n));
+        if (!rc) rc = stage_matrix(c, h_M, d, metric, &M);
+        if (rc) return rc;
+        seeds = c->st_a.p; cand = c->st_b.p; out = c->st_out.p; dist = want_dist ? c->st_dist.p : nullptr;
+        hipError_t e = hipSuccess;
+        if (n_seeds) e = hipMemcpyAsync(seeds, h_seeds, (size_t)n_seeds * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess && n) e = hipMemcpyAsync(cand, h_cand, n * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess && M) e = hipMemcpyAsync(M, h_M, (size_t)d * d * sizeof(float), hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) return fail(BLISSGPU_ERR_HIP, "hipMemcpyAsync(playlist)", hipGetErrorString(e));
         return BLISSGPU_OK;
     }
-    int down(blissgpu_ctx* c, void* h_out, size_t out_bytes, float* h_dist, uint64_t n) {
+    int down(void* h_out, size_t out_bytes, float* h_dist, uint64_t n) {
         hipError_t e = hipSuccess;
         if (out_bytes) e = hipMemcpyAsync(h_out, out, out_bytes, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && h_dist && n) e = hipMemcpyAsync(h_dist, dist, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
@@ -886,6 +495,8 @@ struct PlStage {
 };
 }  // namespace
 
+extern "C" {
+
 int blissgpu_set_distance(const float* seeds, uint32_t n_seeds, const float* cand, uint64_t n, uint32_t d, int metric,
                           const float* M, float* out) {
     int rc = playlist_args_ok("blissgpu_set_distance", seeds, cand, out, n_seeds, n, d, metric, M);
@@ -893,11 +504,11 @@ int blissgpu_set_distance(const float* seeds, uint32_t n_seeds, const float* can
     blissgpu_ctx* c;
     rc = default_ctx(&c);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
-    PlStage s;
-    rc = s.up(c, seeds, n_seeds, cand, n, d, metric, M, n * sizeof(float), false);
+    CTX_ENTER(c, "blissgpu_set_distance");
+    PlStage s{c};
+    rc = s.up(seeds, n_seeds, cand, n, d, metric, M, n * sizeof(float), false);
     if (!rc) rc = blissgpu_set_distance_device(c, s.seeds, n_seeds, s.cand, n, d, metric, s.M, (float*)s.out);
-    if (!rc) rc = s.down(c, out, n * sizeof(float), nullptr, 0);
+    if (!rc) rc = s.down(out, n * sizeof(float), nullptr, 0);
     (void)hipStreamSynchronize(c->stream);
     return rc;
 }
@@ -909,11 +520,11 @@ int blissgpu_closest_to_songs(const float* seeds, uint32_t n_seeds, const float*
     blissgpu_ctx* c;
     rc = default_ctx(&c);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
-    PlStage s;
-    rc = s.up(c, seeds, n_seeds, cand, n, d, metric, M, n * sizeof(uint32_t), dist != nullptr);
+    CTX_ENTER(c, "blissgpu_closest_to_songs");
+    PlStage s{c};
+    rc = s.up(seeds, n_seeds, cand, n, d, metric, M, n * sizeof(uint32_t), dist != nullptr);
     if (!rc) rc = blissgpu_closest_to_songs_device(c, s.seeds, n_seeds, s.cand, n, d, metric, s.M, (uint32_t*)s.out, s.dist);
-    if (!rc) rc = s.down(c, order, n * sizeof(uint32_t), dist, n);
+    if (!rc) rc = s.down(order, n * sizeof(uint32_t), dist, n);
     (void)hipStreamSynchronize(c->stream);
     return rc;
 }
@@ -925,11 +536,11 @@ int blissgpu_song_to_song(const float* seeds, uint32_t n_seeds, const float* can
     blissgpu_ctx* c;
     rc = default_ctx(&c);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
-    PlStage s;
-    rc = s.up(c, seeds, n_seeds, cand, n, d, metric, M, n * sizeof(uint32_t), false);
+    CTX_ENTER(c, "blissgpu_song_to_song");
+    PlStage s{c};
+    rc = s.up(seeds, n_seeds, cand, n, d, metric, M, n * sizeof(uint32_t), false);
     if (!rc) rc = blissgpu_song_to_song_device(c, s.seeds, n_seeds, s.cand, n, d, metric, s.M, (uint32_t*)s.out);
-    if (!rc) rc = s.down(c, order, n * sizeof(uint32_t), nullptr, 0);
+    if (!rc) rc = s.down(order, n * sizeof(uint32_t), nullptr, 0);
     (void)hipStreamSynchronize(c->stream);
     return rc;
 }
@@ -942,13 +553,13 @@ int blissgpu_malloc(void** p, uint64_t bytes) {
 }
 int blissgpu_free(void* p) { HIP_TRY(hipFree(p)); return BLISSGPU_OK; }
 int blissgpu_memcpy_h2d(blissgpu_ctx* c, void* dst, const void* src, uint64_t bytes) {
-    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_memcpy_h2d", "ctx is NULL");
+    CTX_ENTER(c, "blissgpu_memcpy_h2d");
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BLISSGPU_OK;
 }
 int blissgpu_memcpy_d2h(blissgpu_ctx* c, void* dst, const void* src, uint64_t bytes) {
-    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_memcpy_d2h", "ctx is NULL");
+    CTX_ENTER(c, "blissgpu_memcpy_d2h");
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BLISSGPU_OK;
@@ -958,7 +569,7 @@ int blissgpu_synth_white_noise_device(blissgpu_ctx* c, float* d_pcm, const uint6
                                       uint32_t n_songs, uint32_t first_song_index) {
     if (!c || !d_pcm || !offsets || !lengths) return fail(BLISSGPU_ERR_INVALID, "blissgpu_synth_white_noise_device", "NULL argument");
     if (n_songs == 0) return BLISSGPU_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    CTX_ENTER(c, "blissgpu_synth_white_noise_device");
     std::vector<SongDesc> songs(n_songs);
     std::vector<uint32_t> pfx(n_songs + 1, 0);
     for (uint32_t i = 0; i < n_songs; i++) {
@@ -987,14 +598,15 @@ int blissgpu_synth_white_noise_device(blissgpu_ctx* c, float* d_pcm, const uint6
 }
 
 int blissgpu_profile_enable(blissgpu_ctx* c, int enable) {
-    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_profile_enable", "ctx is NULL");
+    CTX_ENTER(c, "blissgpu_profile_enable");
     c->profiling = enable != 0;
     return BLISSGPU_OK;
 }
 
 int blissgpu_profile_reset(blissgpu_ctx* c) {
-    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_profile_reset", "ctx is NULL");
+    CTX_ENTER(c, "blissgpu_profile_reset");
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->aux_stream);
     for (auto& v : c->events) {
         for (auto& ev : v) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
         v.clear();
@@ -1007,7 +619,9 @@ const char* blissgpu_profile_kernel_name(int k) { return (k >= 0 && k < K_COUNT)
 
 int blissgpu_profile_get(blissgpu_ctx* c, int k, double* total_ms, uint64_t* launches) {
     if (!c || k < 0 || k >= K_COUNT) return fail(BLISSGPU_ERR_INVALID, "blissgpu_profile_get", "bad kernel id");
+    CTX_ENTER(c, "blissgpu_profile_get");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->aux_stream));
     double tot = 0.0;
     for (auto& ev : c->events[k]) {
         float ms = 0.0f;
@@ -1019,8 +633,11 @@ int blissgpu_profile_get(blissgpu_ctx* c, int k, double* total_ms, uint64_t* lau
     return BLISSGPU_OK;
 }
 
+uint64_t blissgpu_debug_last_chunks(blissgpu_ctx* c) { return c ? c->last_chunks : 0; }
+
 int blissgpu_debug_last_tuning(blissgpu_ctx* c, double* tuning, uint32_t* n_bpms, uint32_t n_songs) {
     if (!c || n_songs > c->dbg_n) return fail(BLISSGPU_ERR_INVALID, "blissgpu_debug_last_tuning", "no such batch");
+    CTX_ENTER(c, "blissgpu_debug_last_tuning");
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<int32_t> idx(n_songs);
     HIP_TRY(hipMemcpy(idx.data(), c->dbg_tuning.p, n_songs * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1032,24 +649,31 @@ int blissgpu_debug_last_tuning(blissgpu_ctx* c, double* tuning, uint32_t* n_bpms
 }
 
 int blissgpu_debug_fetch(blissgpu_ctx* c, int what, uint32_t song, void* dst, uint64_t max_elems, uint64_t* n_elems) {
-    if (!c || !dst || song >= c->last_songs.size()) return fail(BLISSGPU_ERR_INVALID, "blissgpu_debug_fetch", "no such song in the last chunk");
+    if (!c || !dst) return fail(BLISSGPU_ERR_INVALID, "blissgpu_debug_fetch", "NULL argument");
+    CTX_ENTER(c, "blissgpu_debug_fetch");
+    // `song` is the caller's index into the last batch; the chunk keeps its songs in length order
+    size_t pos = c->last_songs.size();
+    for (size_t i = 0; i < c->last_songs.size(); i++)
+        if (c->last_songs[i].row == song) { pos = i; break; }
+    if (pos == c->last_songs.size()) return fail(BLISSGPU_ERR_INVALID, "blissgpu_debug_fetch", "no such song in the last chunk");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const SongDesc& d = c->last_songs[song];
+    const SongDesc& d = c->last_songs[pos];
     const Workspace& w = c->last_ws;
     const void* src = nullptr;
     uint64_t n = 0, esz = 4;
+    const uint64_t runs = d.ok ? (d.n_b >= (uint32_t)BT_STEP ? (d.n_b - BT_STEP) / BT_STEP + 1 : 0) : 0;
     switch (what) {
         case BLISSGPU_DEBUG_CENTROID: src = w.centroid + d.t_off; n = d.n_t; break;
         case BLISSGPU_DEBUG_ROLLOFF: src = w.rolloff + d.t_off; n = d.n_t; break;
         case BLISSGPU_DEBUG_FLATNESS: src = w.flatness + d.t_off; n = d.n_t; break;
         case BLISSGPU_DEBUG_FLUX: src = w.flux + d.b_off; n = d.n_b; break;
         case BLISSGPU_DEBUG_THRESHOLDED: src = w.thresholded + d.b_off; n = d.n_b; break;
-        case BLISSGPU_DEBUG_RUN_BPM: src = w.run_bpm + (size_t)song * w.runs_pitch; n = d.ok ? (d.n_b >= (uint32_t)BT_STEP ? (d.n_b - BT_STEP) / BT_STEP + 1 : 0) : 0; break;
-        case BLISSGPU_DEBUG_RUN_COUNT: src = w.run_cnt + (size_t)song * w.runs_pitch; n = d.ok ? (d.n_b >= (uint32_t)BT_STEP ? (d.n_b - BT_STEP) / BT_STEP + 1 : 0) : 0; break;
+        case BLISSGPU_DEBUG_RUN_BPM: src = w.run_bpm + pos * w.runs_pitch; n = runs; break;
+        case BLISSGPU_DEBUG_RUN_COUNT: src = w.run_cnt + pos * w.runs_pitch; n = runs; break;
         case BLISSGPU_DEBUG_SPECTROGRAM: src = w.spec + d.c_off * (size_t)CBINS_PAD; n = (uint64_t)d.n_c * CBINS_PAD; break;
         case BLISSGPU_DEBUG_ENERGY256: src = w.e256 + d.e_off; n = d.n_e; break;
         case BLISSGPU_DEBUG_CROSSINGS256: src = w.zc256 + d.e_off; n = d.n_e; break;
-        case BLISSGPU_DEBUG_PITCH_HIST: src = w.hist100 + (size_t)song * N_TUNING; n = N_TUNING; break;
+        case BLISSGPU_DEBUG_PITCH_HIST: src = w.hist100 + pos * N_TUNING; n = N_TUNING; break;
         default: return fail(BLISSGPU_ERR_INVALID, "blissgpu_debug_fetch", "unknown tap");
     }
     if (!d.ok) n = 0;

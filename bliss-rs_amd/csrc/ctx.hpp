@@ -1,0 +1,173 @@
+// ctx.hpp -- host-side state shared by the translation units behind the C ABI (not part of the ABI):
+//   blissgpu.hip   context life cycle, tables, distances, playlist ordering, helpers
+//   scheduler.hip  Song::analyze batches: planning, length-bucketed chunks, the two-slot streaming schedule,
+//                  the host PCM feed and the coalescing front of the single-song entry points
+//   node.hip       one process driving every GPU of the node (RCCL all-gather of the feature rows)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/blissgpu.h"
+#include "internal.hpp"
+
+namespace bg {
+
+int fail(int code, const char* what, const char* detail);  // sets the thread-local last error, returns code
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return ::bg::fail(BLISSGPU_ERR_HIP, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct EventPair { hipEvent_t a, b; };
+
+template <typename T>
+struct DevBuf {  // grow-only device buffer
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    int ensure(size_t n) {
+        if (n <= cap) return BLISSGPU_OK;
+        if (p) (void)hipFree(p);  // hipFree waits for the device: nothing queued can still be using the old block
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e != hipSuccess && want > n) {  // no room for the growth margin: take exactly what is needed
+            (void)hipGetLastError();
+            want = n;
+            e = hipMalloc((void**)&p, want * sizeof(T));
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            return fail(BLISSGPU_ERR_OOM, "hipMalloc", hipGetErrorString(e));
+        }
+        cap = want;
+        return BLISSGPU_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+template <typename T>
+struct PinnedBuf {  // grow-only page-locked host buffer
+    T* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return BLISSGPU_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 4 + 64;
+        hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return fail(BLISSGPU_ERR_OOM, "hipHostMalloc", hipGetErrorString(e)); }
+        cap = want;
+        return BLISSGPU_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// One of the two chunk slots of the streaming schedule: its own workspace slab, descriptor buffers and events, so
+// that chunk k + 1's FFT kernels can start while chunk k's per-song tails (beat tracker, summaries, row assembly)
+// are still running on the aux stream.
+struct ChunkSlot {
+    DevBuf<uint8_t> slab;        // workspace carved per chunk
+    DevBuf<uint8_t> desc;        // SongDesc[] + tile prefix arrays
+    PinnedBuf<uint8_t> h_desc;   // pinned staging of desc
+    hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_stft = nullptr, ev_chroma = nullptr;
+    hipEvent_t ev_desc = nullptr;  // recorded on the main stream after the descriptor copy: the staging area is free
+    hipEvent_t ev_free = nullptr;  // recorded on the aux stream after the row assembly: the slot is free
+    bool used = false;
+};
+
+// Persistent staging of the host-pointer entry points (the PCM feed): two device PCM buffers (+ raw s16 / multi-channel
+// staging), two result buffers, a copy stream and the events that order them.  Grow-only; guarded by the context mutex.
+struct HostFeed {
+    DevBuf<float> pcm[2];
+    DevBuf<uint8_t> raw[2];
+    DevBuf<float> out[2];
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+};
+
+}  // namespace bg
+
+struct blissgpu_ctx {
+    int device = 0;
+    // Every entry point that takes this context holds `mu` while it touches host-side state (staging areas, buffer
+    // growth, events); the host-pointer forms hold it for the whole call (they synchronise before returning anyway).
+    std::recursive_mutex mu;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;      // FFT + chroma chain (the caller-visible stream)
+    hipStream_t aux_stream = nullptr;  // per-song tails: PCM statistics, summaries, beat tracker, row assembly
+    hipEvent_t ev_interop = nullptr;
+    bool serial = false;               // BLISSGPU_SERIAL=1: single stream (clean per-kernel timings)
+    uint64_t ws_limit = 0;             // bytes per chunk slot (set from the free device memory at creation)
+    uint32_t cand_budget = bg::CAND_BUDGET_PER_FRAME;  // tuning-candidate pool: slots per chroma frame of a chunk
+    // tables
+    float2 *tw8192 = nullptr, *tw512 = nullptr;
+    float *hann8192 = nullptr, *hannz512 = nullptr, *bt_rwv = nullptr, *bt_dfwv = nullptr;
+    double* chroma_bank = nullptr;
+    bg::DeviceTables tables{};
+    // analysis
+    bg::ChunkSlot slot[2];
+    uint64_t chunk_seq = 0;            // chunks run so far (slot = chunk_seq & 1)
+    bg::DevBuf<int32_t> dbg_tuning;
+    bg::DevBuf<uint32_t> dbg_nbpms;
+    uint32_t dbg_n = 0;
+    bg::Workspace last_ws{};                 // workspace carving of the last chunk (debug taps)
+    std::vector<bg::SongDesc> last_songs;    // its descriptors (chunk order; SongDesc::row = the caller's song index)
+    uint64_t last_chunks = 0;                // chunks of the last analyze call
+    bg::HostFeed feed;
+    // distances / playlist ordering scratch
+    int n_cus = 0;
+    bg::DevBuf<uint32_t> pl_sync, pl_keys;
+    bg::DevBuf<uint8_t> pl_tmp;
+    bg::DevBuf<unsigned long long> pl_slots;
+    bg::DevBuf<float> st_a, st_b, st_m, st_dist;   // staging of the host-pointer distance / playlist forms
+    bg::DevBuf<uint8_t> st_out;
+    std::vector<float> m_cache;                    // host copy of the matrix in st_m (skip the upload when unchanged)
+    float* h_scalar = nullptr;                     // page-locked word the single-pair kernel writes its result to
+    // profiling
+    bool profiling = false;
+    std::vector<bg::EventPair> events[bg::K_COUNT];
+};
+
+namespace bg {
+
+struct Prof {  // HIP events around one launch, on the stream the kernel is launched on
+    blissgpu_ctx* c;
+    int k;
+    hipStream_t st;
+    EventPair ev{};
+    bool on;
+    Prof(blissgpu_ctx* ctx, int kernel, hipStream_t stream = nullptr)
+        : c(ctx), k(kernel), st(stream ? stream : ctx->stream), on(ctx->profiling) {
+        if (on) {
+            (void)hipEventCreate(&ev.a);
+            (void)hipEventCreate(&ev.b);
+            (void)hipEventRecord(ev.a, st);
+        }
+    }
+    ~Prof() {
+        if (on) {
+            (void)hipEventRecord(ev.b, st);
+            c->events[k].push_back(ev);
+        }
+    }
+};
+
+int default_ctx(blissgpu_ctx** out);  // process-wide context on device 0 (created on first use)
+
+// scheduler.hip
+void scheduler_release(blissgpu_ctx* c);
+// Host PCM feed: song i = ptrs[i] (host memory), lengths[i] FRAMES of `channels` interleaved samples of
+// `bytes_per_sample` (4: f32, 2: s16); channels > 1 are downmixed on the device.
+int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t* lengths, uint32_t n_songs,
+                       int bytes_per_sample, uint32_t channels, uint32_t features_version, float* out, int32_t* status,
+                       const char* who);
+
+}  // namespace bg

@@ -25,6 +25,7 @@ constexpr int MIN_SAMPLES = 8192;         // src/song/mod.rs:417-430
 constexpr int N_TUNING = 100;             // pitch_tuning histogram bins at resolution 0.01
 constexpr int PIP_LO = 57, PIP_HI = 1483; // centre bins visited by pip_track at n_fft=8192 (chroma.rs:302-313)
 constexpr int PIP_MAX_PER_FRAME = 714;    // peaks cannot be adjacent: ceil(1427/2)
+constexpr int CAND_BUDGET_PER_FRAME = 48; // tuning-candidate pool of a chunk: slots per chroma frame (white noise needs ~8; see tune_select_kernel)
 constexpr int H1_BINS = 8192;             // coarse magnitude histogram: f32 bit pattern >> 18
 constexpr int BT_WINLEN = 512, BT_STEP = 128, BT_LAGLEN = 128;  // src/aubio.rs:1337-1341, 920-922
 constexpr int F512_TILE = 512;            // FFT-512 frames per workgroup (16 lane-groups x 32 consecutive frames + 1 halo frame each)
@@ -39,7 +40,6 @@ struct SongDesc {
     uint64_t b_off;     // first tempo frame
     uint64_t c_off;     // first chroma frame
     uint64_t e_off;     // first 256-sample energy block
-    uint64_t cand_off;  // first slot of the song's tuning-candidate list
     uint32_t n_t;       // timbral frames   floor((n-512)/128)+1
     uint32_t n_b;       // tempo frames     floor((n-512)/256)+1
     uint32_t n_f;       // FFT-512 frames actually computed = max(n_t, 2*n_b)
@@ -57,7 +57,8 @@ struct TuningState {
     uint32_t below;        // peaks in coarse bins < b_lo
     uint32_t n_cand;       // candidates appended so far
     int32_t tuning_idx;    // argmax bin (first max); tuning = -0.5 + 0.01*idx ; -1 => tuning 0.0 (no peaks)
-    uint32_t pad0, pad1;
+    uint32_t cand_off;     // first slot of the song's candidates in the chunk's pool
+    uint32_t cand_cap;     // slots granted = peaks inside [b_lo, b_hi]; 0 => the pool was exhausted: tune_final re-scans the records
 };
 
 // Beat-tracker result per song
@@ -120,8 +121,10 @@ struct Workspace {
     TuningState* tuning;    // [n_songs]
     uint32_t* peak_rec;     // [total_c][PIP_MAX_PER_FRAME] per-peak records written by the STFT kernel (see peak_record())
     uint32_t* peak_cnt;     // [total_c] records per frame
-    double* cand_mag;       // [total_cand]
-    uint8_t* cand_pb;       // [total_cand]
+    double* cand_mag;       // [cand_cap] candidate pool of the chunk (slots handed out by tune_select_kernel)
+    uint8_t* cand_pb;       // [cand_cap]
+    uint32_t* cand_cursor;  // [0] next free pool slot
+    uint32_t cand_cap;
     double* chroma_part;    // [total chroma tiles][10] partial sums of interval features
     TempoState* tempo;      // [n_songs]
     float* run_bpm;         // [n_songs][runs_pitch] bpm after each beat-tracker run
@@ -156,10 +159,13 @@ void launch_tune_pass2(const Batch&, const Workspace&, hipStream_t);
 void launch_tune_final(const Batch&, const Workspace&, hipStream_t);
 void launch_chroma(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
 void launch_summary(const Batch&, const Workspace&, hipStream_t);
-void launch_finalize(const Batch&, const Workspace&, uint32_t features_version, float* d_out, int32_t* dbg_tuning,
-                     uint32_t* dbg_nbpms, hipStream_t);
+void launch_finalize(const Batch&, const Workspace&, uint32_t features_version, float* d_out, int32_t* d_status,
+                     int32_t* dbg_tuning, uint32_t* dbg_nbpms, hipStream_t);
 void launch_chroma_bank(double* bank, hipStream_t);
-void launch_pcm_s16_to_f32(const int16_t* in, float* out, uint64_t n, hipStream_t st);
+// raw decoder output -> mono f32: bytes_per_sample 2 (s16, sample / 32768) or 4 (f32), `channels` interleaved
+void launch_pcm_convert(const void* in, int bytes_per_sample, uint32_t channels, float* out, uint64_t frames, hipStream_t st);
+// one pair distance with both vectors passed by value (no staging copies); result -> *out (device-visible host word)
+void launch_pair_distance(const float* a, const float* b, uint32_t d, int metric, const float* d_M, float* out, hipStream_t st);
 // playlist ordering (kernels_playlist.hip)
 void launch_set_distance(const float* seeds, uint32_t n_seeds, const float* cand, uint64_t n, uint32_t d, int metric,
                          const float* M, float* dist, uint32_t* keys, uint32_t* idx, uint32_t* nan_flag, hipStream_t st);

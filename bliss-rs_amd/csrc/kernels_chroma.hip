@@ -560,16 +560,20 @@ void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tune_select_kernel(const SongDesc* __restrict__ songs,
                                                           const uint32_t* __restrict__ h1,
-                                                          TuningState* __restrict__ tuning) {
+                                                          TuningState* __restrict__ tuning,
+                                                          uint32_t* __restrict__ cand_cursor, uint32_t cand_pool) {
     __shared__ uint32_t wsum[4];
-    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_total, s_blo, s_bhi;
     const uint32_t s = blockIdx.x;
     const int tid = threadIdx.x;
     TuningState* ts = tuning + s;
-    if (!songs[s].ok) {
-        if (tid == 0) { ts->n_peaks = 0; ts->tuning_idx = -1; ts->n_cand = 0; ts->b_lo = 1; ts->b_hi = 0; ts->below = 0; }
-        return;
-    }
+    auto no_peaks = [&]() {
+        if (tid == 0) {
+            ts->n_peaks = 0; ts->tuning_idx = -1; ts->n_cand = 0; ts->b_lo = 1; ts->b_hi = 0; ts->below = 0;
+            ts->cand_off = 0; ts->cand_cap = 0;
+        }
+    };
+    if (!songs[s].ok) { no_peaks(); return; }
     const uint32_t* hist = h1 + (size_t)s * H1_BINS;
     constexpr int PER = H1_BINS / 256;  // 32 consecutive bins per thread
     uint32_t local[PER], sum = 0;
@@ -584,10 +588,7 @@ __global__ __launch_bounds__(256) void tune_select_kernel(const SongDesc* __rest
     __syncthreads();
     const uint32_t total = s_total;
     uint32_t before = base + incl - sum;  // peaks in bins below this thread's first bin
-    if (total == 0) {
-        if (tid == 0) { ts->n_peaks = 0; ts->tuning_idx = -1; ts->n_cand = 0; ts->b_lo = 1; ts->b_hi = 0; ts->below = 0; }
-        return;
-    }
+    if (total == 0) { no_peaks(); return; }
     // ndarray-stats Midpoint: lower = floor(0.5*(n-1)), higher = ceil(0.5*(n-1))
     const uint32_t r_lo = (total - 1) / 2, r_hi = total - 1 - r_lo;
     if (tid == 0) { ts->n_peaks = total; ts->n_cand = 0; ts->tuning_idx = -1; }
@@ -595,16 +596,43 @@ __global__ __launch_bounds__(256) void tune_select_kernel(const SongDesc* __rest
     for (int i = 0; i < PER; i++) {
         const uint32_t c = local[i];
         if (c) {
-            if (before <= r_lo && r_lo < before + c) { ts->b_lo = tid * PER + i; ts->below = before; }
-            if (before <= r_hi && r_hi < before + c) ts->b_hi = tid * PER + i;
+            if (before <= r_lo && r_lo < before + c) { ts->b_lo = tid * PER + i; ts->below = before; s_blo = tid * PER + i; }
+            if (before <= r_hi && r_hi < before + c) { ts->b_hi = tid * PER + i; s_bhi = tid * PER + i; }
         }
         before += c;
+    }
+    __syncthreads();
+    // The peaks inside [b_lo, b_hi] are the candidates of the exact select; the histogram already knows how many there
+    // are, so the song takes exactly that many slots from the chunk's pool.  A song the pool cannot serve (cand_cap = 0)
+    // is handled by the re-scan path of tune_final_kernel.
+    const uint32_t blo = s_blo, bhi = s_bhi;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const uint32_t bin = tid * PER + i;
+        if (bin >= blo && bin <= bhi) mine += local[i];
+    }
+    mine = wave_sum(mine);
+    if (lane_id() == 0) wsum[wave_id()] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t want = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const uint32_t off = atomicAdd(cand_cursor, want);
+        if (off <= cand_pool && want <= cand_pool - off) {
+            ts->cand_off = off;
+            ts->cand_cap = want;
+        } else {
+            atomicSub(cand_cursor, want);  // leave the room to the songs that fit
+            ts->cand_off = 0;
+            ts->cand_cap = 0;
+        }
     }
 }
 
 void launch_tune_select(const Batch& b, const Workspace& w, hipStream_t st) {
     if (b.n_songs == 0) return;
-    hipLaunchKernelGGL(tune_select_kernel, dim3(b.n_songs), dim3(256), 0, st, b.songs, w.h1, w.tuning);
+    hipLaunchKernelGGL(tune_select_kernel, dim3(b.n_songs), dim3(256), 0, st, b.songs, w.h1, w.tuning, w.cand_cursor,
+                       w.cand_cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -637,6 +665,8 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
     TuningState* ts = tuning + s;
     const uint32_t b_lo = ts->b_lo, b_hi = ts->b_hi;
     if (ts->n_peaks == 0) return;
+    const uint32_t cand_off = ts->cand_off;
+    const bool pooled = ts->cand_cap != 0;  // false: the pool was exhausted, tune_final re-scans the records instead
     if (tid < N_TUNING) hist[tid] = 0;
     __syncthreads();
     uint32_t n_slow = 0;  // wave-uniform
@@ -655,8 +685,10 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
                     atomicAdd(&hist[pitch_bin(pitch)], 1u);
                 } else if (b >= b_lo) {
                     const uint32_t slot = atomicAdd(&ts->n_cand, 1u);
-                    cand_mag[sd.cand_off + slot] = mag;
-                    cand_pb[sd.cand_off + slot] = (uint8_t)pitch_bin(pitch);
+                    if (pooled) {
+                        cand_mag[cand_off + slot] = mag;
+                        cand_pb[cand_off + slot] = (uint8_t)pitch_bin(pitch);
+                    }
                 }
             }
         }
@@ -706,17 +738,18 @@ void launch_tune_pass2(const Batch& b, const Workspace& w, hipStream_t st) {
 // tuning final: exact order statistics among the candidates (8-bit MSD radix select on the
 // order-preserving u64 image of the f64 magnitudes), Midpoint threshold, histogram, first argmax
 // ------------------------------------------------------------------------------------------------
-__device__ uint64_t block_radix_select(const double* __restrict__ v, uint32_t n, uint32_t rank, uint32_t* hist,
-                                       uint32_t* s_digit, uint32_t* s_rank) {
+// for_each(fn) calls fn(magnitude, pitch bin) for every candidate of the song, spread over the 256 threads
+template <typename ForEach>
+__device__ uint64_t block_radix_select(ForEach&& for_each, uint32_t rank, uint32_t* hist, uint32_t* s_digit, uint32_t* s_rank) {
     const int tid = threadIdx.x;
     uint64_t prefix = 0, mask = 0;
     for (int shift = 56; shift >= 0; shift -= 8) {
         hist[tid] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += 256) {
-            const uint64_t k = f64_key(v[i]);
+        for_each([&](double mag, int) {
+            const uint64_t k = f64_key(mag);
             if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFF], 1u);
-        }
+        });
         __syncthreads();
         if (tid == 0) {
             uint32_t acc = 0, d = 0;
@@ -740,7 +773,11 @@ __global__ __launch_bounds__(256) void tune_final_kernel(const SongDesc* __restr
                                                          TuningState* __restrict__ tuning,
                                                          const uint32_t* __restrict__ hist100,
                                                          const double* __restrict__ cand_mag,
-                                                         const uint8_t* __restrict__ cand_pb) {
+                                                         const uint8_t* __restrict__ cand_pb,
+                                                         const float* __restrict__ spec,
+                                                         const float* __restrict__ frame_max,
+                                                         const uint32_t* __restrict__ peak_rec,
+                                                         const uint32_t* __restrict__ peak_cnt) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_digit, s_rank, s_cnt_le;
     __shared__ unsigned long long s_min_gt;
@@ -752,10 +789,36 @@ __global__ __launch_bounds__(256) void tune_final_kernel(const SongDesc* __restr
     const uint32_t total = ts->n_peaks, nc = ts->n_cand;
     const uint32_t r_lo = (total - 1) / 2, r_hi = total - 1 - r_lo;
     const uint32_t k_lo = r_lo - ts->below, k_hi = r_hi - ts->below;
-    const double* v = cand_mag + sd.cand_off;
-    const uint8_t* pb = cand_pb + sd.cand_off;
+    const uint32_t b_lo = ts->b_lo, b_hi = ts->b_hi;
+    const bool pooled = ts->cand_cap != 0;
+    const double* v = cand_mag + ts->cand_off;
+    const uint8_t* pb = cand_pb + ts->cand_off;
 
-    const uint64_t key_lo = block_radix_select(v, nc, k_lo, hist, &s_digit, &s_rank);
+    // Candidates: the pool slots tuning pass 2 filled -- or, for a song the pool could not serve, the same peaks
+    // re-derived from the peak records and the stored spectrogram (identical arithmetic, pip_peak_core): slower by the
+    // nine passes over the records, taken only by songs whose peaks crowd into the median's coarse magnitude bins
+    // (e.g. click tracks: a flat spectrum) in a chunk whose pool is already full.
+    auto for_each = [&](auto&& fn) {
+        if (pooled) {
+            for (uint32_t i = tid; i < nc; i += 256) fn(v[i], (int)pb[i]);
+        } else {
+            for (uint32_t f = 0; f < sd.n_c; f++) {
+                const uint32_t n_rec = peak_cnt[sd.c_off + f];
+                const uint32_t* __restrict__ recs = peak_rec + (sd.c_off + f) * (size_t)PIP_MAX_PER_FRAME;
+                const float* __restrict__ row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
+                const double ref = 0.1 * (double)frame_max[sd.c_off + f];
+                for (uint32_t j = tid; j < n_rec; j += 256) {
+                    const uint32_t r = recs[j], b = r >> 18;
+                    if (b < b_lo || b > b_hi) continue;
+                    const int c = (int)(r & 0x7FFu);
+                    double mag, pitch;
+                    if (pip_peak_core(row[c - 1], row[c], row[c + 1], ref, c, &mag, &pitch)) fn(mag, pitch_bin(pitch));
+                }
+            }
+        }
+    };
+
+    const uint64_t key_lo = block_radix_select(for_each, k_lo, hist, &s_digit, &s_rank);
     uint64_t key_hi = key_lo;
     if (k_hi != k_lo) {
         // the next order statistic: key_lo again if it is repeated, else the smallest key above it
@@ -763,11 +826,11 @@ __global__ __launch_bounds__(256) void tune_final_kernel(const SongDesc* __restr
         __syncthreads();
         uint32_t cnt = 0;
         unsigned long long mn = ~0ull;
-        for (uint32_t i = tid; i < nc; i += 256) {
-            const uint64_t k = f64_key(v[i]);
+        for_each([&](double mag, int) {
+            const uint64_t k = f64_key(mag);
             if (k <= key_lo) cnt++;
             else if (k < mn) mn = k;
-        }
+        });
         atomicAdd(&s_cnt_le, cnt);
         atomicMin(&s_min_gt, mn);
         __syncthreads();
@@ -782,8 +845,9 @@ __global__ __launch_bounds__(256) void tune_final_kernel(const SongDesc* __restr
     __syncthreads();
     if (tid < N_TUNING) hist[tid] = hist100[(size_t)s * N_TUNING + tid];
     __syncthreads();
-    for (uint32_t i = tid; i < nc; i += 256)
-        if (v[i] >= thr) atomicAdd(&hist[pb[i]], 1u);
+    for_each([&](double mag, int bin) {
+        if (mag >= thr) atomicAdd(&hist[bin], 1u);
+    });
     __syncthreads();
     if (tid == 0) {
         uint32_t best = 0;  // ndarray-stats argmax keeps the first maximum
@@ -796,7 +860,7 @@ __global__ __launch_bounds__(256) void tune_final_kernel(const SongDesc* __restr
 void launch_tune_final(const Batch& b, const Workspace& w, hipStream_t st) {
     if (b.n_songs == 0) return;
     hipLaunchKernelGGL(tune_final_kernel, dim3(b.n_songs), dim3(256), 0, st, b.songs, w.tuning, w.hist100,
-                       w.cand_mag, w.cand_pb);
+                       w.cand_mag, w.cand_pb, w.spec, w.frame_max, w.peak_rec, w.peak_cnt);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,6 +1,8 @@
 // kernels_finalize.hip -- per-song summaries and assembly of the feature row
-// (compiled with -ffp-contract=off: the summaries below follow the reference's scalar f32
-// evaluation order bit for bit, so the only GPU/CPU difference left is FFT rounding).
+// (compiled with -ffp-contract=off: the timbral summaries below follow the reference's scalar f32
+// evaluation order bit for bit, so the only GPU/CPU difference left there is FFT rounding; the
+// loudness chunks are assembled from 256-sample lane-tree partial sums, i.e. they match the
+// reference's sequential 1024-sample sums to rounding, not bit for bit).
 //
 //   mean  : utils::mean (src/utils.rs:66-68), sequential f32 sum / len
 //   std   : ndarray std_axis(ddof = 0): Welford with one fused mul_add (src/timbral.rs:61-63 ...)
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(const SongDesc* __restrict
                                                       const TempoState* __restrict__ tempo,
                                                       const TuningState* __restrict__ tuning,
                                                       uint32_t features_version, float* __restrict__ out,
+                                                      int32_t* __restrict__ status,
                                                       int32_t* __restrict__ dbg_tuning,
                                                       uint32_t* __restrict__ dbg_nbpms) {
     const uint32_t s = blockIdx.x * 64 + threadIdx.x;
@@ -132,6 +135,8 @@ __global__ __launch_bounds__(64) void assemble_kernel(const SongDesc* __restrict
     const SongDesc sd = songs[s];
     const uint32_t d = features_version == 1 ? 20 : 23;
     float* o = out + (size_t)sd.row * d;
+    // per-song status, 1:1 with BlissError (BLISSGPU_SONG_OK / BLISSGPU_SONG_TOO_SHORT, src/song/mod.rs:417-430)
+    if (status) status[sd.row] = sd.ok ? 0 : 1;
     if (!sd.ok) {
         for (uint32_t k = 0; k < d; k++) o[k] = __int_as_float(0x7fc00000);  // NaN row; status says why
         dbg_tuning[sd.row] = -1;
@@ -176,11 +181,11 @@ void launch_summary(const Batch& b, const Workspace& w, hipStream_t st) {
                        w.rolloff, w.flatness, w.e256, w.zc256, w.summary);
 }
 
-void launch_finalize(const Batch& b, const Workspace& w, uint32_t features_version, float* d_out, int32_t* dbg_tuning,
-                     uint32_t* dbg_nbpms, hipStream_t st) {
+void launch_finalize(const Batch& b, const Workspace& w, uint32_t features_version, float* d_out, int32_t* d_status,
+                     int32_t* dbg_tuning, uint32_t* dbg_nbpms, hipStream_t st) {
     if (b.n_songs == 0) return;
     hipLaunchKernelGGL(assemble_kernel, dim3((b.n_songs + 63) / 64), dim3(64), 0, st, b.songs, b.n_songs, b.pfx_ct,
-                       w.summary, w.chroma_part, w.tempo, w.tuning, features_version, d_out, dbg_tuning, dbg_nbpms);
+                       w.summary, w.chroma_part, w.tempo, w.tuning, features_version, d_out, d_status, dbg_tuning, dbg_nbpms);
 }
 
 }  // namespace bg

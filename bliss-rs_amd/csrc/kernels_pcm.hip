@@ -108,28 +108,52 @@ void launch_pcm_stats(const Batch& b, const Workspace& w, hipStream_t st) {
                        w.e256, w.zc256);
 }
 
-// ---- s16 -> f32 on the device: sample / 32768 (exact in f32), FFmpeg's AV_SAMPLE_FMT_S16 -> FLT conversion as used by
-// the reference's decoder (src/song/decoder/ffmpeg.rs:36-109); halves the PCIe bytes of the PCM feed ----
-__global__ __launch_bounds__(256) void pcm_s16_to_f32_kernel(const int16_t* __restrict__ in, float* __restrict__ out, uint64_t n) {
-    const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (i + 8 <= n && ((reinterpret_cast<uintptr_t>(in + i) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out + i) & 15) == 0)) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(in + i);  // 8 samples
-        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-        float4 lo, hi;
-        lo.x = (float)(int16_t)(w[0] & 0xFFFF) * (1.0f / 32768.0f); lo.y = (float)(int16_t)(w[0] >> 16) * (1.0f / 32768.0f);
-        lo.z = (float)(int16_t)(w[1] & 0xFFFF) * (1.0f / 32768.0f); lo.w = (float)(int16_t)(w[1] >> 16) * (1.0f / 32768.0f);
-        hi.x = (float)(int16_t)(w[2] & 0xFFFF) * (1.0f / 32768.0f); hi.y = (float)(int16_t)(w[2] >> 16) * (1.0f / 32768.0f);
-        hi.z = (float)(int16_t)(w[3] & 0xFFFF) * (1.0f / 32768.0f); hi.w = (float)(int16_t)(w[3] >> 16) * (1.0f / 32768.0f);
-        *reinterpret_cast<float4*>(out + i) = lo;
-        *reinterpret_cast<float4*>(out + i + 4) = hi;
+// ---- raw decoder output -> the mono f32 PCM Song::analyze takes (the PCM feed) ----
+//   s16 -> f32   : sample / 32768 (exact in f32), FFmpeg's AV_SAMPLE_FMT_S16 -> FLT conversion as used by the reference's
+//                  decoder (src/song/decoder/ffmpeg.rs:36-109); halves the PCIe bytes of the feed
+//   stereo -> mono: (L + R) * SQRT_2 / 2 in f32, in exactly this order (src/song/decoder/symphonia.rs:281-285; "recovers
+//                  the exact behavior of ffmpeg": both decoders pin the result on data/s16_stereo_22_5kHz.flac to
+//                  Adler-32 0x1d7b2d6d, ffmpeg.rs:448-452, symphonia.rs:594-610)
+//   > 2 channels : sequential f32 sum / channel count (symphonia.rs:291-297)
+__device__ __forceinline__ float pcm_sample(const int16_t* p, uint64_t i) { return (float)p[i] * (1.0f / 32768.0f); }
+__device__ __forceinline__ float pcm_sample(const float* p, uint64_t i) { return p[i]; }
+
+template <typename SampleT>
+__global__ __launch_bounds__(256) void pcm_convert_kernel(const SampleT* __restrict__ in, uint32_t channels,
+                                                          float* __restrict__ out, uint64_t frames) {
+#pragma clang fp contract(off)
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= frames) return;
+    float r[4];
+    const int nf = frames - i0 < 4 ? (int)(frames - i0) : 4;
+    if (channels == 1) {
+        for (int k = 0; k < nf; k++) r[k] = pcm_sample(in, i0 + k);
+    } else if (channels == 2) {
+        for (int k = 0; k < nf; k++) {
+            const float l = pcm_sample(in, 2 * (i0 + k)), rr = pcm_sample(in, 2 * (i0 + k) + 1);
+            r[k] = (l + rr) * 1.41421356237309504880f / 2.0f;
+        }
     } else {
-        for (uint64_t k = i; k < n && k < i + 8; k++) out[k] = (float)in[k] * (1.0f / 32768.0f);
+        for (int k = 0; k < nf; k++) {
+            float acc = 0.0f;
+            for (uint32_t c = 0; c < channels; c++) acc = acc + pcm_sample(in, (uint64_t)channels * (i0 + k) + c);
+            r[k] = acc / (float)channels;
+        }
+    }
+    if (nf == 4 && ((reinterpret_cast<uintptr_t>(out + i0) & 15) == 0)) {
+        *reinterpret_cast<float4*>(out + i0) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+        for (int k = 0; k < nf; k++) out[i0 + k] = r[k];
     }
 }
 
-void launch_pcm_s16_to_f32(const int16_t* in, float* out, uint64_t n, hipStream_t st) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(pcm_s16_to_f32_kernel, dim3((uint32_t)((n + 2047) / 2048)), dim3(256), 0, st, in, out, n);
+void launch_pcm_convert(const void* in, int bytes_per_sample, uint32_t channels, float* out, uint64_t frames, hipStream_t st) {
+    if (frames == 0) return;
+    const dim3 grid((uint32_t)((frames + 1023) / 1024));
+    if (bytes_per_sample == 2)
+        hipLaunchKernelGGL(pcm_convert_kernel<int16_t>, grid, dim3(256), 0, st, (const int16_t*)in, channels, out, frames);
+    else
+        hipLaunchKernelGGL(pcm_convert_kernel<float>, grid, dim3(256), 0, st, (const float*)in, channels, out, frames);
 }
 
 // ---- synthetic white noise: uniform [-0.5, 0.5), Philox4x32-10, key = (0x5EED0000 + song, 0),

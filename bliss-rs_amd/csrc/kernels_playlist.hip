@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void song_to_song_kernel(const float* __restri
                                                            int metric, const float* __restrict__ M,
                                                            uint32_t* __restrict__ order,
                                                            unsigned long long* slots,  // [2][gridDim.x]
-                                                           uint32_t* sync) {           // [0] barrier, [1] NaN flag
+                                                           uint32_t* sync) {           // [0] barrier, [1] NaN flag (for the host)
     __shared__ unsigned long long red[4];
     __shared__ unsigned long long s_win;
     __shared__ float s_cur[PL_DMAX];
@@ -176,7 +176,12 @@ __global__ __launch_bounds__(256) void song_to_song_kernel(const float* __restri
                 visit(c, j);
             }
         }
-        if (saw_nan) __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // A NaN distance (the reference panics there) travels THROUGH the barrier protocol as the reserved slot value 0
+        // (no valid key is 0: the image of -inf is 0x007FFFFF): every workgroup reduces the same G slots after the same
+        // barrier, so the exit below is taken by all of them at the same step.  (A side flag read outside the barrier
+        // could be seen by a slower workgroup one step early, which then never arrives at the barrier the faster ones
+        // are already spinning on.)
+        if (saw_nan) best = 0ull;
         best = wave_min_u64(best);
         if (lane == 0) red[wave] = best;
         __syncthreads();
@@ -205,7 +210,10 @@ __global__ __launch_bounds__(256) void song_to_song_kernel(const float* __restri
             s_win = b;
         }
         __syncthreads();
-        if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // NaN: uniform exit
+        if (s_win == 0ull) {  // NaN: grid-uniform exit
+            if (wg == 0 && tid == 0) __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         const uint32_t win = (uint32_t)(s_win & 0xFFFFFFFFull);
         if (wg == 0 && tid == 0) order[step] = win;
         if (win % T == gtid) alive &= ~(1ull << (win / T));
@@ -229,6 +237,21 @@ void launch_song_to_song(const float* seeds, uint32_t n_seeds, const float* cand
     else if (d == 20 && per <= 4) S2S(20, 4);
     else S2S(1, 0);
 #undef S2S
+}
+
+// ---- one pair, both vectors passed BY VALUE in the kernel arguments: Song::distance / Analysis::distance
+// (src/song/mod.rs:364-370, 519-521) without staging copies; the result goes to a page-locked host word ----
+struct PairArgs { float a[PL_DMAX]; float b[PL_DMAX]; };
+
+__global__ __launch_bounds__(64) void pair_distance_kernel(PairArgs p, uint32_t d, int metric, const float* __restrict__ M,
+                                                           float* __restrict__ out) {
+    if (threadIdx.x == 0) *out = pl_distance(p.a, p.b, d, metric, M);
+}
+
+void launch_pair_distance(const float* a, const float* b, uint32_t d, int metric, const float* d_M, float* out, hipStream_t st) {
+    PairArgs p;
+    for (uint32_t k = 0; k < (uint32_t)PL_DMAX; k++) { p.a[k] = k < d ? a[k] : 0.0f; p.b[k] = k < d ? b[k] : 0.0f; }
+    hipLaunchKernelGGL(pair_distance_kernel, dim3(1), dim3(64), 0, st, p, d, metric, d_M, out);
 }
 
 }  // namespace bg

@@ -1,0 +1,568 @@
+// scheduler.hip -- batches of Song::analyze on the device: the GPU replacement of the reference's per-song thread pool
+// (Decoder::analyze_paths_with_options, src/song/decoder.rs:278-332) and of the five per-descriptor threads of one
+// analysis (src/song/mod.rs:432-491).
+//
+//   plan      songs are ordered by length (longest first: "length bucketing") and cut into chunks whose scratch
+//             workspace fits one of the context's TWO chunk slots;
+//   schedule  chunk k runs its FFT / chroma chain on the context's main stream and its per-song tails (PCM statistics,
+//             sequential summaries, beat tracker, row assembly) on the aux stream.  Nothing on the main stream ever
+//             waits for a tail, so chunk k + 1's FFT kernels start right behind chunk k's chroma contraction while
+//             chunk k's tails are still running; a slot is reused two chunks later, after its own assembly;
+//   feed      host PCM (f32 or s16, mono or interleaved multi-channel) is shipped group by group into two device
+//             buffers, the copy of group g + 1 overlapping the analysis of group g;
+//   front     concurrent single-song calls (N worker threads each calling Song::analyze, src/song/decoder.rs:299-329)
+//             are coalesced: whoever holds the run lock analyses every request that queued up behind it as ONE batch.
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+
+#include "ctx.hpp"
+
+using namespace bg;
+
+namespace {
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// host-side frame counts; must agree with the reference's framing
+void fill_counts(SongDesc& d) {
+    const uint64_t n = d.n;
+    d.n_t = (uint32_t)((n - W512) / HOP_T + 1);
+    d.n_b = (uint32_t)((n - W512) / HOP_B + 1);
+    d.n_f = std::max(d.n_t, 2u * d.n_b);
+    // src/utils.rs:29-32: rows = (len as f32 / hop as f32).ceil(); the zip with windows() caps it at n/hop + 1
+    const uint32_t rows = (uint32_t)ceilf((float)n / (float)HOP_C);
+    d.n_c = (uint32_t)std::min<uint64_t>(rows, n / HOP_C + 1);
+    d.n_e = (uint32_t)((n + 255) / 256);
+    d.n_l = (uint32_t)((n + LOUD_W - 1) / LOUD_W);
+}
+
+// scratch bytes one song adds to a chunk (upper bound of the carving below, alignment slack included)
+size_t song_ws_bytes(const SongDesc& d) {
+    if (!d.ok) return 256;
+    size_t b = 0;
+    b += (size_t)d.n_t * 12 + (size_t)d.n_b * 8 + (size_t)d.n_e * 8;
+    b += (size_t)d.n_c * (CBINS_PAD * 4 + 4);
+    b += (size_t)H1_BINS * 4 + N_TUNING * 4 + sizeof(TuningState) + sizeof(TempoState);
+    b += (size_t)d.n_c * CAND_BUDGET_PER_FRAME * 9;
+    b += (size_t)d.n_c * (PIP_MAX_PER_FRAME * 4 + 4);
+    b += ((size_t)d.n_c / CH_TILE + 1) * 80;
+    b += ((size_t)d.n_b / BT_STEP + 2) * 8;
+    return b + 4096;
+}
+
+struct Carver {
+    uint8_t* base;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = reinterpret_cast<T*>(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+struct ChunkTotals {
+    uint64_t tot_t = 0, tot_b = 0, tot_c = 0, tot_e = 0;
+    uint32_t max_nb = 0, max_nt = 0, max_runs = 1;
+    uint32_t tiles_ct = 0;
+    uint64_t cand_cap = 0;
+};
+
+Workspace carve(uint8_t* base, uint32_t ns, const ChunkTotals& t, size_t* bytes) {
+    Carver m{base};
+    Workspace w{};
+    w.centroid = m.take<float>(t.tot_t); w.rolloff = m.take<float>(t.tot_t); w.flatness = m.take<float>(t.tot_t);
+    w.flux = m.take<float>(t.tot_b); w.thresholded = m.take<float>(t.tot_b);
+    w.e256 = m.take<float>(t.tot_e); w.zc256 = m.take<uint32_t>(t.tot_e);
+    w.spec = m.take<float>(t.tot_c * CBINS_PAD + 64); w.frame_max = m.take<float>(t.tot_c);
+    w.h1 = m.take<uint32_t>((size_t)ns * H1_BINS); w.hist100 = m.take<uint32_t>((size_t)ns * N_TUNING);
+    w.tuning = m.take<TuningState>(ns);
+    w.peak_rec = m.take<uint32_t>(t.tot_c * PIP_MAX_PER_FRAME); w.peak_cnt = m.take<uint32_t>(t.tot_c);
+    w.cand_mag = m.take<double>(t.cand_cap); w.cand_pb = m.take<uint8_t>(t.cand_cap);
+    w.cand_cursor = m.take<uint32_t>(4);
+    w.cand_cap = (uint32_t)t.cand_cap;
+    w.chroma_part = m.take<double>((size_t)t.tiles_ct * 10 + 16);
+    w.tempo = m.take<TempoState>(ns);
+    w.run_bpm = m.take<float>((size_t)ns * t.max_runs); w.run_cnt = m.take<uint32_t>((size_t)ns * t.max_runs);
+    w.runs_pitch = t.max_runs;
+    w.summary = m.take<float>((size_t)ns * 16);
+    *bytes = m.off + 4096;
+    return w;
+}
+
+int ensure_slot_events(ChunkSlot& s) {
+    if (s.ev_free) return BLISSGPU_OK;
+    hipEvent_t* evs[] = {&s.ev_start, &s.ev_fork, &s.ev_stft, &s.ev_chroma, &s.ev_desc, &s.ev_free};
+    for (hipEvent_t* e : evs) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return BLISSGPU_OK;
+}
+
+// One chunk = the songs [songs, songs + ns) (already ordered).  Everything is enqueued; nothing here waits for the
+// device except the reuse of a slot's pinned descriptor staging (two chunks back) and buffer growth.
+int run_chunk(blissgpu_ctx* c, const float* d_pcm, SongDesc* songs, uint32_t ns, uint32_t features_version, float* d_out,
+              int32_t* d_status) {
+    if (ns == 0) return BLISSGPU_OK;
+    ChunkSlot& slot = c->slot[c->chunk_seq & 1];
+    int rc = ensure_slot_events(slot);
+    if (rc) return rc;
+    // ---- offsets into the batch-wide series + tile prefixes ----
+    std::vector<uint32_t> pfx_e(ns + 1, 0), pfx_f(ns + 1, 0), pfx_c(ns + 1, 0), pfx_ct(ns + 1, 0), pfx_cw(ns + 1, 0);
+    ChunkTotals t;
+    for (uint32_t i = 0; i < ns; i++) {
+        SongDesc& d = songs[i];
+        d.t_off = t.tot_t; d.b_off = t.tot_b; d.c_off = t.tot_c; d.e_off = t.tot_e;
+        if (d.ok) {
+            t.tot_t += d.n_t; t.tot_b += d.n_b; t.tot_c += d.n_c; t.tot_e += d.n_e;
+            t.max_nb = std::max(t.max_nb, d.n_b);
+            t.max_nt = std::max(t.max_nt, d.n_t);
+            t.max_runs = std::max(t.max_runs, d.n_b / BT_STEP + 1);
+        }
+        pfx_e[i + 1] = pfx_e[i] + (d.ok ? (d.n_e + 15) / 16 : 0);
+        pfx_f[i + 1] = pfx_f[i] + (d.ok ? (d.n_f + F512_TILE - 1) / F512_TILE : 0);
+        pfx_c[i + 1] = pfx_c[i] + (d.ok ? (d.n_c + STFT_TILE - 1) / STFT_TILE : 0);
+        pfx_ct[i + 1] = pfx_ct[i] + (d.ok ? (d.n_c + CH_TILE - 1) / CH_TILE : 0);
+        pfx_cw[i + 1] = pfx_cw[i] + (d.ok ? (d.n_c + 4 * CH_TILE - 1) / (4 * CH_TILE) : 0);
+    }
+    t.tiles_ct = pfx_ct[ns];
+    // Tuning candidates (the peaks inside the median's coarse magnitude bins) come from one pool per chunk, handed out
+    // on the device once the histogram says how many each song has; a song the pool cannot serve takes the exact
+    // re-scan path of tune_final_kernel instead.
+    t.cand_cap = std::min<uint64_t>(t.tot_c * (uint64_t)c->cand_budget, 0xFFFFFF00ull) + 64;
+
+    // ---- buffers of the slot (growth frees the old block, which waits for the device) ----
+    const size_t desc_bytes = align_up(ns * sizeof(SongDesc), 256) + 5 * align_up((ns + 1) * 4, 256);
+    size_t need = 0;
+    (void)carve(nullptr, ns, t, &need);
+    if ((rc = slot.desc.ensure(desc_bytes))) return rc;
+    if ((rc = slot.slab.ensure(need))) return rc;
+    if (slot.used) HIP_TRY(hipEventSynchronize(slot.ev_desc));  // the slot's previous descriptor copy has left the staging area
+    if ((rc = slot.h_desc.ensure(desc_bytes))) return rc;
+
+    hipStream_t st = c->stream, sb = c->serial ? c->stream : c->aux_stream;
+    const bool two = !c->serial;
+    // the slot's previous chunk (two chunks back) must have assembled its rows before its workspace is overwritten
+    if (slot.used && two) HIP_TRY(hipStreamWaitEvent(st, slot.ev_free, 0));
+
+    uint8_t* h = slot.h_desc.p;
+    size_t o = 0;
+    const size_t o_songs = o; memcpy(h + o, songs, ns * sizeof(SongDesc)); o = align_up(o + ns * sizeof(SongDesc), 256);
+    const size_t o_e = o; memcpy(h + o, pfx_e.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
+    const size_t o_f = o; memcpy(h + o, pfx_f.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
+    const size_t o_c = o; memcpy(h + o, pfx_c.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
+    const size_t o_ct = o; memcpy(h + o, pfx_ct.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
+    const size_t o_cw = o; memcpy(h + o, pfx_cw.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
+    HIP_TRY(hipMemcpyAsync(slot.desc.p, h, o, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(slot.ev_desc, st));
+    slot.used = true;
+
+    Batch b{};
+    b.pcm = d_pcm;
+    b.songs = reinterpret_cast<const SongDesc*>(slot.desc.p + o_songs);
+    b.n_songs = ns;
+    b.pfx_e = reinterpret_cast<const uint32_t*>(slot.desc.p + o_e);
+    b.pfx_f = reinterpret_cast<const uint32_t*>(slot.desc.p + o_f);
+    b.pfx_c = reinterpret_cast<const uint32_t*>(slot.desc.p + o_c);
+    b.pfx_ct = reinterpret_cast<const uint32_t*>(slot.desc.p + o_ct);
+    b.pfx_cw = reinterpret_cast<const uint32_t*>(slot.desc.p + o_cw);
+    b.tiles_e = pfx_e[ns]; b.tiles_f = pfx_f[ns]; b.tiles_c = pfx_c[ns]; b.tiles_ct = pfx_ct[ns]; b.tiles_cw = pfx_cw[ns];
+    b.total_b = t.tot_b; b.max_nb = t.max_nb; b.max_nt = t.max_nt;
+
+    size_t used_bytes = 0;
+    const Workspace w = carve(slot.slab.p, ns, t, &used_bytes);
+    c->last_ws = w;
+    c->last_songs.assign(songs, songs + ns);
+
+    // The reference runs the five descriptors as scoped threads (src/song/mod.rs:432-491).  Here the two FFT-heavy
+    // kernels and the chroma chain run back to back on the main stream; the latency-bound tails of the tempo / timbral /
+    // loudness chains (one workgroup or one lane per song) and the row assembly run on the aux stream.
+    HIP_TRY(hipMemsetAsync(w.h1, 0, (size_t)ns * H1_BINS * 4, st));
+    HIP_TRY(hipMemsetAsync(w.hist100, 0, (size_t)ns * N_TUNING * 4, st));
+    HIP_TRY(hipMemsetAsync(w.cand_cursor, 0, 16, st));
+    if (two) {
+        HIP_TRY(hipEventRecord(slot.ev_start, st));
+        HIP_TRY(hipStreamWaitEvent(sb, slot.ev_start, 0));
+    }
+    // aux: the HBM-bound PCM statistics pass (only the tails consume it) runs beside the VALU-bound FFT-512
+    { Prof p(c, K_PCM_STATS, sb); launch_pcm_stats(b, w, sb); }
+    { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st); }
+    { Prof p(c, K_ONSET); launch_onset(b, w, st); }
+    // aux: the sequential summaries (one lane per song, memory-latency bound) start as soon as the FFT-512 series
+    // exist and run beside the FFT-8192 kernel
+    if (two) {
+        HIP_TRY(hipEventRecord(slot.ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(sb, slot.ev_fork, 0));
+    }
+    { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
+    { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st); }
+    // The beat tracker (one 256-thread workgroup per song) would displace FFT-8192 workgroups, so it starts only after
+    // that kernel and runs beside the HBM-bound tuning / chroma kernels -- and, in a multi-chunk batch, beside the next
+    // chunk's FFT-512.
+    if (two) {
+        HIP_TRY(hipEventRecord(slot.ev_stft, st));
+        HIP_TRY(hipStreamWaitEvent(sb, slot.ev_stft, 0));
+    }
+    { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
+    { Prof p(c, K_TUNE_SELECT); launch_tune_select(b, w, st); }
+    { Prof p(c, K_TUNE_PASS2); launch_tune_pass2(b, w, st); }
+    { Prof p(c, K_TUNE_FINAL); launch_tune_final(b, w, st); }
+    { Prof p(c, K_CHROMA); launch_chroma(b, w, c->tables, st); }
+    if (two) {
+        HIP_TRY(hipEventRecord(slot.ev_chroma, st));
+        HIP_TRY(hipStreamWaitEvent(sb, slot.ev_chroma, 0));
+    }
+    { Prof p(c, K_FINALIZE, sb); launch_finalize(b, w, features_version, d_out, d_status, c->dbg_tuning.p, c->dbg_nbpms.p, sb); }
+    if (two) HIP_TRY(hipEventRecord(slot.ev_free, sb));
+    HIP_TRY(hipGetLastError());
+    c->chunk_seq++;
+    return BLISSGPU_OK;
+}
+
+}  // namespace
+
+namespace bg {
+
+void scheduler_release(blissgpu_ctx* c) {
+    for (ChunkSlot& s : c->slot) {
+        s.slab.release(); s.desc.release(); s.h_desc.release();
+        hipEvent_t evs[] = {s.ev_start, s.ev_fork, s.ev_stft, s.ev_chroma, s.ev_desc, s.ev_free};
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
+        s = ChunkSlot{};
+    }
+    HostFeed& f = c->feed;
+    if (f.copy_stream) { (void)hipStreamSynchronize(f.copy_stream); (void)hipStreamDestroy(f.copy_stream); f.copy_stream = nullptr; }
+    for (int b = 0; b < 2; b++) {
+        f.pcm[b].release(); f.raw[b].release(); f.out[b].release();
+        if (f.ev_copied[b]) (void)hipEventDestroy(f.ev_copied[b]);
+        if (f.ev_done[b]) (void)hipEventDestroy(f.ev_done[b]);
+        f.ev_copied[b] = f.ev_done[b] = nullptr;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Host PCM feed.  Songs are packed group by group into one of TWO device PCM buffers; the H2D copies
+// of group g + 1 run on the copy stream while group g is analysed, so the transfer -- the real bottleneck of these
+// entry points (a 3-minute song is 15.9 MB as f32, 7.9 MB as s16) -- is never idle.  s16 samples are widened on the
+// device (sample / 32768 = FFmpeg's s16 -> flt, src/song/decoder/ffmpeg.rs:36-109) and interleaved channels are
+// downmixed there ((L + R) * SQRT_2 / 2 for stereo, the channel mean otherwise: src/song/decoder/symphonia.rs:266-300).
+// All staging lives in the context and is reused by later calls.
+// ------------------------------------------------------------------------------------------------------------------
+int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t* lengths, uint32_t n_songs,
+                       int bytes_per_sample, uint32_t channels, uint32_t features_version, float* out, int32_t* status,
+                       const char* who) {
+    const uint32_t d = blissgpu_feature_count(features_version);
+    if (!d) return fail(BLISSGPU_ERR_INVALID, who, "features_version must be 1 or 2");
+    if (channels == 0 || channels > 8) return fail(BLISSGPU_ERR_INVALID, who, "channels must be 1..8");
+    if (n_songs == 0) return BLISSGPU_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HostFeed& f = c->feed;
+    if (!f.copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&f.copy_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIP_TRY(hipEventCreateWithFlags(&f.ev_copied[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&f.ev_done[b], hipEventDisableTiming));
+        }
+    }
+    const bool direct = bytes_per_sample == 4 && channels == 1;  // f32 mono: copied verbatim into the PCM buffer
+    const size_t frame_bytes = (size_t)bytes_per_sample * channels;
+    // groups of <= 2 GiB of mono f32 PCM (~128 three-minute songs): large enough to fill the GPU, small enough to pipeline
+    const uint64_t group_cap = 512ull << 20;  // frames
+    struct Group { uint32_t i0, n; std::vector<uint64_t> doff, dlen; uint64_t total; };
+    std::vector<Group> groups;
+    for (uint32_t i0 = 0; i0 < n_songs;) {
+        Group g{i0, 0, {}, {}, 0};
+        uint32_t i1 = i0;
+        while (i1 < n_songs && (i1 == i0 || g.total + lengths[i1] <= group_cap)) {
+            g.doff.push_back(g.total);
+            g.dlen.push_back(lengths[i1]);
+            g.total += (lengths[i1] + 63) / 64 * 64;
+            i1++;
+        }
+        g.n = i1 - i0;
+        groups.push_back(std::move(g));
+        i0 = i1;
+    }
+    uint64_t max_total = 64, max_n = 1;
+    for (const auto& g : groups) { max_total = std::max(max_total, g.total); max_n = std::max<uint64_t>(max_n, g.n); }
+    const int nbuf = groups.size() > 1 ? 2 : 1;
+    int rc = BLISSGPU_OK;
+    for (int b = 0; b < nbuf && !rc; b++) {
+        rc = f.pcm[b].ensure(max_total);
+        if (!rc && !direct) rc = f.raw[b].ensure(max_total * frame_bytes);
+        if (!rc) rc = f.out[b].ensure(max_n * d);
+    }
+    if (rc) return rc;
+
+    auto upload = [&](size_t gi) -> hipError_t {  // H2D of group gi into buffer gi % nbuf, on the copy stream
+        const Group& g = groups[gi];
+        const int b = (int)(gi % nbuf);
+        // buffer b is free again once the analysis that last read it (this call's group gi - 2, or an earlier call:
+        // every call ends synchronised) has finished
+        hipError_t ee = gi >= (size_t)nbuf ? hipStreamWaitEvent(f.copy_stream, f.ev_done[b], 0) : hipSuccess;
+        for (uint32_t k = 0; k < g.n && ee == hipSuccess; k++)
+            if (g.dlen[k]) {
+                void* dst = direct ? (void*)(f.pcm[b].p + g.doff[k]) : (void*)(f.raw[b].p + g.doff[k] * frame_bytes);
+                ee = hipMemcpyAsync(dst, ptrs[g.i0 + k], g.dlen[k] * frame_bytes, hipMemcpyHostToDevice, f.copy_stream);
+            }
+        if (ee == hipSuccess) ee = hipEventRecord(f.ev_copied[b], f.copy_stream);
+        return ee;
+    };
+
+    hipError_t e = upload(0);
+    for (size_t gi = 0; gi < groups.size() && e == hipSuccess && !rc; gi++) {
+        const Group& g = groups[gi];
+        const int b = (int)(gi % nbuf);
+        e = hipStreamWaitEvent(c->stream, f.ev_copied[b], 0);
+        if (e != hipSuccess) break;
+        if (!direct) {
+            launch_pcm_convert(f.raw[b].p, bytes_per_sample, channels, f.pcm[b].p, g.total, c->stream);
+            e = hipGetLastError();
+            if (e != hipSuccess) break;
+        }
+        rc = blissgpu_analyze_batch_device(c, f.pcm[b].p, g.doff.data(), g.dlen.data(), g.n, features_version, f.out[b].p, nullptr);
+        if (rc) break;
+        e = hipMemcpyAsync(out + (size_t)g.i0 * d, f.out[b].p, (size_t)g.n * d * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(f.ev_done[b], c->stream);
+        // the next group's transfer overlaps this group's kernels (pageable sources block the host here, not the GPU)
+        if (e == hipSuccess && gi + 1 < groups.size()) e = upload(gi + 1);
+        if (status)
+            for (uint32_t k = 0; k < g.n; k++)
+                status[g.i0 + k] = g.dlen[k] >= (uint64_t)MIN_SAMPLES ? BLISSGPU_SONG_OK : BLISSGPU_SONG_TOO_SHORT;
+    }
+    // every exit leaves the streams drained: the staging buffers belong to the next call
+    const hipError_t e1 = hipStreamSynchronize(f.copy_stream), e2 = hipStreamSynchronize(c->stream);
+    if (rc) return rc;
+    if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
+    if (e != hipSuccess) return fail(BLISSGPU_ERR_HIP, who, hipGetErrorString(e));
+    return BLISSGPU_OK;
+}
+
+}  // namespace bg
+
+// ------------------------------------------------------------------------------------------------------------------
+// Coalescing front of the single-song entry points.  The reference's bulk path is N worker threads each calling
+// Song::analyze on its own song (src/song/decoder.rs:299-329); one song cannot fill the GPU, a batch can.  A caller
+// queues its request and takes the run lock; whoever holds the lock analyses EVERYTHING that queued up behind it as one
+// batch (group commit).  A lone caller pays no waiting window; under load the batch size adapts to the arrival rate.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct AnalyzeReq {
+    const void* pcm;
+    uint64_t frames;
+    int bytes_per_sample;
+    uint32_t channels, version;
+    float* out;
+    int32_t status = BLISSGPU_SONG_OK;
+    int rc = BLISSGPU_OK;
+    std::string err;
+    bool done = false;
+};
+
+std::mutex g_q_mu;
+std::vector<AnalyzeReq*> g_queue;
+std::mutex g_run_mu;
+
+int submit(AnalyzeReq& r, const char* who) {
+    { std::lock_guard<std::mutex> lk(g_q_mu); g_queue.push_back(&r); }
+    std::vector<AnalyzeReq*> take;
+    {
+        std::lock_guard<std::mutex> run(g_run_mu);
+        {
+            std::lock_guard<std::mutex> lk(g_q_mu);
+            if (!r.done) take.swap(g_queue);  // r itself is in there: it was queued before the run lock was taken
+        }
+        if (!take.empty()) {
+            blissgpu_ctx* c = nullptr;
+            int rc0 = default_ctx(&c);
+            // one device batch per (sample format, channels, features version) class; in practice there is one class
+            std::vector<char> served(take.size(), 0);
+            for (size_t a = 0; a < take.size(); a++) {
+                if (served[a]) continue;
+                std::vector<size_t> cls;
+                for (size_t q = a; q < take.size(); q++)
+                    if (!served[q] && take[q]->bytes_per_sample == take[a]->bytes_per_sample &&
+                        take[q]->channels == take[a]->channels && take[q]->version == take[a]->version) {
+                        cls.push_back(q);
+                        served[q] = 1;
+                    }
+                const uint32_t d = blissgpu_feature_count(take[a]->version);
+                std::vector<const void*> ptrs(cls.size());
+                std::vector<uint64_t> lens(cls.size());
+                std::vector<int32_t> st(cls.size(), 0);
+                std::vector<float> rows(cls.size() * (size_t)std::max(d, 1u));
+                for (size_t q = 0; q < cls.size(); q++) { ptrs[q] = take[cls[q]]->pcm; lens[q] = take[cls[q]]->frames; }
+                int rc = rc0 ? rc0
+                             : analyze_host_songs(c, ptrs.data(), lens.data(), (uint32_t)cls.size(), take[a]->bytes_per_sample,
+                                                  take[a]->channels, take[a]->version, rows.data(), st.data(), who);
+                const std::string err = rc ? blissgpu_last_error() : "";
+                for (size_t q = 0; q < cls.size(); q++) {
+                    AnalyzeReq* t = take[cls[q]];
+                    t->rc = rc;
+                    t->err = err;
+                    t->status = st[q];
+                    if (!rc) memcpy(t->out, rows.data() + q * d, d * sizeof(float));
+                }
+            }
+            std::lock_guard<std::mutex> lk(g_q_mu);
+            for (AnalyzeReq* t : take) t->done = true;
+        }
+    }
+    if (r.rc) return fail(r.rc, who, r.err.c_str());
+    return BLISSGPU_OK;
+}
+
+int analyze_one(const void* pcm, uint64_t frames, int bytes, uint32_t channels, uint32_t version, float* out,
+                int32_t* status, const char* who) {
+    if (!out || (frames && !pcm)) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
+    if (!blissgpu_feature_count(version)) return fail(BLISSGPU_ERR_INVALID, who, "features_version must be 1 or 2");
+    if (channels == 0 || channels > 8) return fail(BLISSGPU_ERR_INVALID, who, "channels must be 1..8");
+    AnalyzeReq r{pcm, frames, bytes, channels, version, out};
+    const int rc = submit(r, who);
+    if (status) *status = r.status;
+    return rc;
+}
+
+int batch_from_offsets(const void* pcm, size_t frame_bytes, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
+                       int bytes, uint32_t channels, uint32_t version, float* out, int32_t* status, const char* who) {
+    if (n_songs && (!pcm || !offsets || !lengths || !out)) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
+    if (!blissgpu_feature_count(version)) return fail(BLISSGPU_ERR_INVALID, who, "features_version must be 1 or 2");
+    if (n_songs == 0) return BLISSGPU_OK;
+    blissgpu_ctx* c;
+    int rc = default_ctx(&c);
+    if (rc) return rc;
+    std::vector<const void*> ptrs(n_songs);
+    for (uint32_t i = 0; i < n_songs; i++) ptrs[i] = (const uint8_t*)pcm + offsets[i] * frame_bytes;
+    return analyze_host_songs(c, ptrs.data(), lengths, n_songs, bytes, channels, version, out, status, who);
+}
+
+}  // namespace
+
+extern "C" {
+
+int blissgpu_analyze_batch_device(blissgpu_ctx* c, const float* d_pcm, const uint64_t* offsets, const uint64_t* lengths,
+                                  uint32_t n_songs, uint32_t features_version, float* d_out, int32_t* d_status) {
+    if (!c || (n_songs && (!d_pcm || !offsets || !lengths || !d_out)))
+        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_batch_device", "NULL argument");
+    if (features_version != BLISSGPU_FEATURES_V1 && features_version != BLISSGPU_FEATURES_V2)
+        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_batch_device", "features_version must be 1 or 2");
+    if (n_songs == 0) return BLISSGPU_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->dbg_tuning.ensure(n_songs))) return rc;
+    if ((rc = c->dbg_nbpms.ensure(n_songs))) return rc;
+    c->dbg_n = n_songs;
+
+    // ---- plan: descriptors in length order (longest first).  Songs of one chunk then have similar lengths, so the
+    // 64 lanes of a summary wavefront and the beat-tracker workgroups of a chunk finish together, and the longest
+    // tails start first.  Equal lengths keep the caller's order (stable). ----
+    std::vector<SongDesc> songs(n_songs);
+    for (uint32_t i = 0; i < n_songs; i++) {
+        SongDesc& d = songs[i];
+        d = SongDesc{};
+        d.pcm_off = offsets[i];
+        d.n = lengths[i];
+        d.row = i;
+        d.ok = lengths[i] >= (uint64_t)MIN_SAMPLES;  // src/song/mod.rs:417-430
+        if (d.ok) fill_counts(d);
+    }
+    std::stable_sort(songs.begin(), songs.end(), [](const SongDesc& a, const SongDesc& b) { return a.n > b.n; });
+    // ---- chunks: as many songs as fit one slot's workspace ----
+    struct Range { uint32_t b, e; };
+    std::vector<Range> todo;
+    {
+        size_t bytes = 0;
+        uint32_t b0 = 0;
+        for (uint32_t i = 0; i < n_songs; i++) {
+            const size_t sb = song_ws_bytes(songs[i]);
+            if (i > b0 && bytes + sb > c->ws_limit) { todo.push_back({b0, i}); b0 = i; bytes = 0; }
+            bytes += sb;
+        }
+        todo.push_back({b0, n_songs});
+    }
+    std::reverse(todo.begin(), todo.end());  // used as a stack
+    uint64_t chunks = 0;
+    while (!todo.empty()) {
+        const Range r = todo.back();
+        todo.pop_back();
+        rc = run_chunk(c, d_pcm, songs.data() + r.b, r.e - r.b, features_version, d_out, d_status);
+        if (rc == BLISSGPU_ERR_OOM && r.e - r.b > 1) {
+            // the device has less free memory than the limit assumed (another process, the caller's own tensors):
+            // halve the chunk and go on
+            (void)hipGetLastError();
+            const uint32_t mid = r.b + (r.e - r.b) / 2;
+            todo.push_back({mid, r.e});
+            todo.push_back({r.b, mid});
+            continue;
+        }
+        if (rc) return rc;
+        chunks++;
+    }
+    c->last_chunks = chunks;
+    // the caller-visible stream has "done" everything once the tails of the (at most two) chunks in flight are in
+    if (!c->serial)
+        for (ChunkSlot& s : c->slot)
+            if (s.used) HIP_TRY(hipStreamWaitEvent(c->stream, s.ev_free, 0));
+    return BLISSGPU_OK;
+}
+
+int blissgpu_analyze_batch(const float* pcm, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
+                           uint32_t features_version, float* out, int32_t* status) {
+    return batch_from_offsets(pcm, 4, offsets, lengths, n_songs, 4, 1, features_version, out, status, "blissgpu_analyze_batch");
+}
+
+int blissgpu_analyze_batch_s16(const int16_t* pcm, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
+                               uint32_t features_version, float* out, int32_t* status) {
+    return batch_from_offsets(pcm, 2, offsets, lengths, n_songs, 2, 1, features_version, out, status, "blissgpu_analyze_batch_s16");
+}
+
+int blissgpu_analyze_batch_interleaved(const void* pcm, int sample_format, uint32_t channels, const uint64_t* offsets,
+                                       const uint64_t* lengths, uint32_t n_songs, uint32_t features_version, float* out,
+                                       int32_t* status) {
+    if (sample_format != BLISSGPU_SAMPLE_F32 && sample_format != BLISSGPU_SAMPLE_S16)
+        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_batch_interleaved", "sample_format must be F32 or S16");
+    if (channels == 0 || channels > 8) return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_batch_interleaved", "channels must be 1..8");
+    const int bytes = sample_format == BLISSGPU_SAMPLE_F32 ? 4 : 2;
+    return batch_from_offsets(pcm, (size_t)bytes * channels, offsets, lengths, n_songs, bytes, channels, features_version, out,
+                              status, "blissgpu_analyze_batch_interleaved");
+}
+
+int blissgpu_analyze(const float* pcm, uint64_t len, uint32_t features_version, float* out, int32_t* status) {
+    return analyze_one(pcm, len, 4, 1, features_version, out, status, "blissgpu_analyze");
+}
+
+int blissgpu_analyze_interleaved(const void* pcm, int sample_format, uint32_t channels, uint64_t frames,
+                                 uint32_t features_version, float* out, int32_t* status) {
+    if (sample_format != BLISSGPU_SAMPLE_F32 && sample_format != BLISSGPU_SAMPLE_S16)
+        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_interleaved", "sample_format must be F32 or S16");
+    return analyze_one(pcm, frames, sample_format == BLISSGPU_SAMPLE_F32 ? 4 : 2, channels, features_version, out, status,
+                       "blissgpu_analyze_interleaved");
+}
+
+int blissgpu_pcm_s16_to_f32_device(blissgpu_ctx* c, const int16_t* d_in, uint64_t n, float* d_out) {
+    if (!c || (n && (!d_in || !d_out))) return fail(BLISSGPU_ERR_INVALID, "blissgpu_pcm_s16_to_f32_device", "NULL argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    launch_pcm_convert(d_in, 2, 1, d_out, n, c->stream);
+    HIP_TRY(hipGetLastError());
+    return BLISSGPU_OK;
+}
+
+int blissgpu_pcm_downmix_device(blissgpu_ctx* c, const void* d_in, int sample_format, uint32_t channels, uint64_t frames,
+                                float* d_out) {
+    if (!c || (frames && (!d_in || !d_out))) return fail(BLISSGPU_ERR_INVALID, "blissgpu_pcm_downmix_device", "NULL argument");
+    if ((sample_format != BLISSGPU_SAMPLE_F32 && sample_format != BLISSGPU_SAMPLE_S16) || channels == 0 || channels > 8)
+        return fail(BLISSGPU_ERR_INVALID, "blissgpu_pcm_downmix_device", "bad sample_format / channels");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    launch_pcm_convert(d_in, sample_format == BLISSGPU_SAMPLE_F32 ? 4 : 2, channels, d_out, frames, c->stream);
+    HIP_TRY(hipGetLastError());
+    return BLISSGPU_OK;
+}
+
+}  // extern "C"

@@ -90,27 +90,28 @@ class Decoder(abc.ABC):
 
 
 class RawPcmDecoder(Decoder):
-    """Decoder for already-decoded PCM: `.npy` (float32 mono 22 050 Hz, or int16 scaled by 1/32768 like
-    ffmpeg's s16 -> flt conversion) and 22 050 Hz mono 16-bit `.wav`."""
+    """Decoder for already-decoded 22 050 Hz PCM: `.npy` (float32 or int16; 1-D mono or [frames, channels]) and 16-bit
+    `.wav` (any channel count).  int16 samples and extra channels are passed on as they are: the s16 -> f32 widening
+    (sample / 32768, FFmpeg's conversion) and the mono downmix ((L + R) * SQRT_2 / 2, src/song/decoder/symphonia.rs:
+    281-285) run on the device.  Resampling is not done: other sample rates are a DecodingError."""
 
     @classmethod
     def decode(cls, path: str) -> PreAnalyzedSong:
         try:
             if path.endswith(".npy"):
                 a = np.load(path)
-                if a.dtype == np.int16:
-                    a = a.astype(np.float32) / np.float32(32768.0)
-                if a.ndim != 1:
-                    raise DecodingError("expected mono samples")
-                samples = a.astype(np.float32)
+                if a.ndim not in (1, 2) or (a.ndim == 2 and not 1 <= a.shape[1] <= 8):
+                    raise DecodingError("expected [frames] or [frames, channels <= 8] samples")
+                samples = a if a.dtype == np.int16 else a.astype(np.float32)
             else:
                 with wave.open(path, "rb") as w:
-                    if w.getframerate() != SAMPLE_RATE or w.getnchannels() != 1 or w.getsampwidth() != 2:
-                        raise DecodingError("only 22050 Hz mono s16 wav is supported by RawPcmDecoder")
-                    samples = (np.frombuffer(w.readframes(w.getnframes()), "<i2").astype(np.float32)
-                               / np.float32(32768.0))
+                    if w.getframerate() != SAMPLE_RATE or w.getsampwidth() != 2 or not 1 <= w.getnchannels() <= 8:
+                        raise DecodingError("only 22050 Hz s16 wav is supported by RawPcmDecoder")
+                    samples = np.frombuffer(w.readframes(w.getnframes()), "<i2")
+                    if w.getnchannels() > 1:
+                        samples = samples.reshape(-1, w.getnchannels())
         except BlissError:
             raise
         except Exception as e:
             raise DecodingError(f"while opening format for file '{path}': {e}")
-        return PreAnalyzedSong(path=path, sample_array=samples, duration=len(samples) / SAMPLE_RATE)
+        return PreAnalyzedSong(path=path, sample_array=samples, duration=samples.shape[0] / SAMPLE_RATE)

@@ -59,7 +59,15 @@ class Context:
         _ffi.check(self._L.blissgpu_ctx_synchronize(self._h))
 
     def set_workspace_limit(self, nbytes: int):
+        """Scratch bytes of ONE chunk slot; larger batches stream through the two slots in length-bucketed chunks."""
         _ffi.check(self._L.blissgpu_ctx_set_workspace_limit(self._h, nbytes))
+
+    def workspace_limit(self) -> int:
+        return int(self._L.blissgpu_ctx_get_workspace_limit(self._h))
+
+    def last_chunks(self) -> int:
+        """Chunks the last analyze() call was cut into."""
+        return int(self._L.blissgpu_debug_last_chunks(self._h))
 
     # ---- analysis ----
     def analyze(self, pcm, offsets: Sequence[int], lengths: Sequence[int], features_version: int = 2, out=None,
@@ -149,6 +157,22 @@ class Context:
         self._post()
         return out
 
+    def pcm_downmix(self, pcm, out=None):
+        """On-device mono downmix of interleaved [frames, channels] decoder output (int16 or float32): stereo ->
+        (L + R) * SQRT_2 / 2, more channels -> their mean (src/song/decoder/symphonia.rs:266-300)."""
+        torch = self.torch
+        assert pcm.is_cuda and pcm.dim() == 2 and pcm.dtype in (torch.int16, torch.float32)
+        pcm = pcm.contiguous()
+        frames, channels = pcm.shape
+        if out is None:
+            out = torch.empty((frames,), dtype=torch.float32, device=pcm.device)
+        fmt = _ffi.SAMPLE_S16 if pcm.dtype == torch.int16 else _ffi.SAMPLE_F32
+        self._pre()
+        _ffi.check(self._L.blissgpu_pcm_downmix_device(self._h, C.c_void_p(pcm.data_ptr()), fmt, channels, frames,
+                                                       C.c_void_p(out.data_ptr())))
+        self._post()
+        return out
+
     # ---- playlist ordering on device-resident feature matrices (src/playlist.rs:24-59, 256-326) ----
     def _pl_args(self, seeds, cand, M):
         torch = self.torch
@@ -223,3 +247,81 @@ class Context:
             if n.value:
                 res[self._L.blissgpu_profile_kernel_name(k).decode()] = (ms.value, n.value)
         return res
+
+
+class Node:
+    """blissgpu_node wrapper: ONE process driving several GPUs (RCCL all-gather of the feature rows inside the
+    library).  The one-process-per-GPU form on torch.distributed is bliss_rs_amd.shard."""
+
+    def __init__(self, n_devices: int = 1, devices: Optional[Sequence[int]] = None):
+        self._L = _ffi.lib()
+        h = C.c_void_p()
+        dev = (C.c_int * n_devices)(*devices) if devices is not None else None
+        _ffi.check(self._L.blissgpu_node_create(n_devices, dev, C.byref(h)))
+        self._h = h
+        self.n_devices = n_devices
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.blissgpu_node_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def shard(self, lengths) -> np.ndarray:
+        lengths = _u64(lengths)
+        ranks = np.empty(len(lengths), np.uint32)
+        _ffi.check(self._L.blissgpu_node_shard(self._h, lengths.ctypes.data_as(C.POINTER(C.c_uint64)), len(lengths),
+                                               ranks.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return ranks
+
+    def row_block(self, n_rows: int, rank: int):
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self._L.blissgpu_node_row_block(self._h, n_rows, rank, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def analyze(self, pcm: np.ndarray, offsets, lengths, features_version: int = 2):
+        """Host PCM -> ([n, d] float32, int32 status); the gathered matrix stays on every device for pairwise()."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        offsets, lengths = _u64(offsets), _u64(lengths)
+        n = len(offsets)
+        d = 23 if features_version == 2 else 20
+        out = np.empty((n, d), np.float32)
+        status = np.empty(n, np.int32)
+        _ffi.check(self._L.blissgpu_node_analyze(self._h, pcm.ctypes.data, offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                 lengths.ctypes.data_as(C.POINTER(C.c_uint64)), n, features_version,
+                                                 out.ctypes.data, status.ctypes.data_as(C.POINTER(C.c_int32))))
+        _ffi.check(self._L.blissgpu_node_synchronize(self._h))
+        self._n, self._d = n, d
+        return out, status
+
+    def analyze_device(self, d_pcm_ptrs: Sequence[int], offsets, lengths, rank_of_song, features_version: int = 2):
+        """Device-resident PCM: song i lives on device rank_of_song[i] at d_pcm_ptrs[rank] + offsets[i] (raw pointers)."""
+        offsets, lengths = _u64(offsets), _u64(lengths)
+        ranks = np.ascontiguousarray(rank_of_song, np.uint32)
+        ptrs = (C.c_void_p * self.n_devices)(*[C.c_void_p(int(p)) for p in d_pcm_ptrs])
+        _ffi.check(self._L.blissgpu_node_analyze_device(self._h, ptrs, offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                        lengths.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                        ranks.ctypes.data_as(C.POINTER(C.c_uint32)), len(offsets),
+                                                        features_version))
+        _ffi.check(self._L.blissgpu_node_synchronize(self._h))
+        self._n, self._d = len(offsets), 23 if features_version == 2 else 20
+
+    def features(self, rank: int = 0) -> np.ndarray:
+        """The gathered matrix as held by `rank`'s device."""
+        out = np.empty((self._n, self._d), np.float32)
+        ctx = self._L.blissgpu_node_ctx(self._h, rank)
+        src = self._L.blissgpu_node_features(self._h, rank)
+        _ffi.check(self._L.blissgpu_memcpy_d2h(ctx, out.ctypes.data, src, out.nbytes))
+        return out
+
+    def pairwise(self, metric: str = "euclidean", M: Optional[np.ndarray] = None) -> np.ndarray:
+        from .playlist import _METRICS
+
+        out = np.empty((self._n, self._n), np.float32)
+        Mp = None
+        if M is not None:
+            M = np.ascontiguousarray(M, np.float32)
+            Mp = M.ctypes.data
+        _ffi.check(self._L.blissgpu_node_pairwise(self._h, _METRICS[metric], Mp, out.ctypes.data))
+        return out

@@ -10,7 +10,10 @@ two without re-analysing anything:
     load_songs            the same rows as `Song` objects (metadata + Analysis)
     store_song            the write path of `store_song` (src/library.rs:1560-1630): upsert the song row, replace
                           its feature rows
-    create_schema         the two tables, for new databases (the crate's migrations are not reproduced)
+    create_schema         the two tables, for new databases (user_version = the number of migrations)
+    upgrade               `Library::upgrade` (src/library.rs:631-681): brings a database written by an older bliss-rs to
+                          the current schema (track_number text -> integer, disc_number, training_triplet,
+                          version not null default 1), keyed on `pragma user_version` like the crate
 
 SQLite stores `real` as f64; an f32 feature widens exactly on the way in and narrows exactly on the way out, so a
 round trip is bit-exact.  Pure host code: nothing here touches the GPU.
@@ -50,7 +53,69 @@ def create_schema(db: Conn) -> None:
                 id integer primary key, song_id integer not null, feature real not null, feature_index integer not null,
                 unique(song_id, feature_index), foreign key(song_id) references song(id) on delete cascade);
             """)
+        conn.execute("pragma user_version = 5")  # = len(SQLITE_MIGRATIONS): a new database needs no migration
         conn.commit()
+    finally:
+        if own:
+            conn.close()
+
+
+# SQLITE_MIGRATIONS of the crate (src/library.rs:532-606), by schema version; the statements are the schema contract an
+# existing library file obeys, so they are restated as they are.
+_MIGRATIONS = (
+    "",
+    """
+    alter table song add column track_number_1 integer;
+    update song set track_number_1 = s1.cast_track_number from (
+        select cast(track_number as int) as cast_track_number, id from song
+    ) as s1 where s1.id = song.id and cast(track_number as int) != 0;
+    alter table song drop column track_number;
+    alter table song rename column track_number_1 to track_number;
+    """,
+    "alter table song add column disc_number integer;",
+    """
+    create table training_triplet (
+        id integer primary key, song_1_id integer not null, song_2_id integer not null,
+        odd_one_out_id integer not null, stamp timestamp default current_timestamp,
+        foreign key(song_1_id) references song(id) on delete cascade,
+        foreign key(song_2_id) references song(id) on delete cascade,
+        foreign key(odd_one_out_id) references song(id) on delete cascade)
+    """,
+    """
+    create table song_bak (
+        id integer primary key, path text not null unique, duration float, album_artist text, artist text,
+        title text, album text, track_number integer, disc_number integer, genre text, cue_path text,
+        audio_file_path text, stamp timestamp default current_timestamp, version integer not null,
+        analyzed boolean default false, extra_info json, error text);
+    insert into song_bak (id, path, duration, album_artist, artist, title, album, track_number, disc_number, genre,
+                          cue_path, audio_file_path, stamp, version, analyzed, extra_info, error)
+        select id, path, duration, album_artist, artist, title, album, track_number, disc_number, genre, cue_path,
+               audio_file_path, stamp, coalesce(version, 1), analyzed, extra_info, error from song;
+    drop table song;
+    alter table song_bak rename to song;
+    """,
+)
+
+
+def upgrade(db: Conn) -> int:
+    """`Library::upgrade` (src/library.rs:631-681): run the migrations an older database is missing; returns the schema
+    version it ends at (5).  A database newer than this mirror is a ProviderError, an empty one gets the current schema."""
+    conn, own = _connect(db)
+    try:
+        version = conn.execute("pragma user_version").fetchone()[0]
+        if version > len(_MIGRATIONS):
+            raise ProviderError(f"bliss-rs version {version} is older than the schema version {len(_MIGRATIONS)}")
+        if version == len(_MIGRATIONS):
+            return version
+        tables = conn.execute("select count(*) from sqlite_master where type = 'table'").fetchone()[0]
+        if version == 0 and tables == 0:
+            create_schema(conn)
+        else:
+            for migration in _MIGRATIONS[version:]:
+                conn.executescript(migration)
+        conn.execute(f"pragma user_version = {len(_MIGRATIONS)}")
+        conn.commit()
+        return len(_MIGRATIONS)
     finally:
         if own:
             conn.close()
@@ -73,9 +138,15 @@ def load_feature_matrix(db: Conn, features_version: FeaturesVersion = FeaturesVe
     ids = np.array([s[0] for s in songs], np.int64)
     feats = np.array([r[0] for r in rows], np.float64)
     owner = np.array([r[1] for r in rows], np.int64)
-    if feats.size != ids.size * d or (ids.size and not np.array_equal(owner.reshape(ids.size, d), np.repeat(ids[:, None], d, 1))):
-        # Analysis::new fails in the crate when a song does not carry exactly feature_count() features
-        raise ProviderError(f"Feature count does not match the expected version feature count {d}")
+    # _songs_from_statement (src/library.rs:1297-1345) groups the feature rows by song id and Analysis::new rejects a
+    # song that does not carry exactly feature_count() of them, naming the first offender
+    counts = {int(i): 0 for i in ids}
+    for o in owner:
+        counts[int(o)] = counts.get(int(o), 0) + 1
+    for (song_id, path) in songs:
+        if counts.get(int(song_id), 0) != d:
+            raise ProviderError(f"Song with ID {song_id} and path {path} has a different feature number than expected. "
+                                "Please rescan or update the song library.")
     return ids, [s[1] for s in songs], feats.astype(np.float32).reshape(ids.size, d)
 
 

@@ -155,39 +155,64 @@ class Analysis:
 
 
 def _as_pcm(sample_array) -> np.ndarray:
+    """Decoder output as the library takes it: int16 stays int16 (widened on the device with sample / 32768, FFmpeg's
+    s16 -> flt conversion), everything else becomes float32; 1-D = mono, 2-D = [frames, channels] interleaved
+    (downmixed on the device like the reference's decoders, src/song/decoder/symphonia.rs:266-300)."""
     a = np.asarray(sample_array)
-    if a.dtype == np.int16:  # s16 PCM: FFmpeg's s16 -> flt conversion (exact in f32)
-        return (a.astype(np.float32) / np.float32(32768.0)).reshape(-1)
-    return np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    if a.dtype != np.int16:
+        a = a.astype(np.float32, copy=False)
+    if a.ndim == 2 and a.shape[1] == 1:
+        a = a[:, 0]
+    if a.ndim not in (1, 2):
+        raise ProviderError("sample arrays must be 1-D (mono) or 2-D [frames, channels]")
+    return np.ascontiguousarray(a)
 
 
 def analyze_batch(sample_arrays: Sequence[np.ndarray], options: Optional[AnalysisOptions] = None):
     """Bulk Song::analyze_with_options: one GPU batch, per-song result (Analysis or BlissError), like the
-    (path, BlissResult<Song>) pairs of analyze_paths_with_options (src/song/decoder.rs:278-332)."""
+    (path, BlissResult<Song>) pairs of analyze_paths_with_options (src/song/decoder.rs:278-332).  A single song goes
+    through blissgpu_analyze[_interleaved], whose concurrent callers (threads each analysing one song, as the
+    reference's worker pool does, src/song/decoder.rs:299-329) are coalesced into one device batch."""
     options = options or AnalysisOptions()
     version = FeaturesVersion(options.features_version)
-    sample_arrays = list(sample_arrays)
-    n = len(sample_arrays)
+    arrays = [_as_pcm(a) for a in sample_arrays]
+    n = len(arrays)
     if n == 0:
         return []
-    # int16 input (decoders that deliver s16 mono 22 050 Hz) crosses PCIe as 2 bytes per sample and is widened on the
-    # device exactly like FFmpeg's s16 -> flt conversion (sample / 32768); anything else is taken as f32 PCM
-    s16 = all(isinstance(a, np.ndarray) and a.dtype == np.int16 for a in sample_arrays)
-    arrays = [np.ascontiguousarray(a).reshape(-1) for a in sample_arrays] if s16 else [_as_pcm(a) for a in sample_arrays]
-    lengths = np.array([len(a) for a in arrays], np.uint64)
-    offsets = np.zeros(n, np.uint64)
-    offsets[1:] = np.cumsum(lengths)[:-1]
-    pcm = np.concatenate(arrays) if n > 1 else arrays[0]
-    if pcm.size == 0:
-        pcm = np.zeros(1, np.int16 if s16 else np.float32)
     d = version.feature_count()
     out = np.empty((n, d), np.float32)
     status = np.empty(n, np.int32)
     L = _ffi.lib()
-    fn = L.blissgpu_analyze_batch_s16 if s16 else L.blissgpu_analyze_batch
-    _ffi.check(fn(pcm.ctypes.data, offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
-                  lengths.ctypes.data_as(C.POINTER(C.c_uint64)), n, int(version),
-                  out.ctypes.data, status.ctypes.data_as(C.POINTER(C.c_int32))))
+    # one device batch per (sample format, channel count) class -- normally there is exactly one
+    classes = {}
+    for i, a in enumerate(arrays):
+        classes.setdefault((a.dtype == np.int16, 1 if a.ndim == 1 else a.shape[1]), []).append(i)
+    for (s16, channels), idx in classes.items():
+        fmt = _ffi.SAMPLE_S16 if s16 else _ffi.SAMPLE_F32
+        if len(idx) == 1:
+            a = arrays[idx[0]]
+            buf = a if a.size else np.zeros(1, a.dtype)
+            row = np.empty(d, np.float32)
+            st = C.c_int32(0)
+            _ffi.check(L.blissgpu_analyze_interleaved(buf.ctypes.data, fmt, channels, a.shape[0], int(version),
+                                                      row.ctypes.data, C.byref(st)))
+            out[idx[0]] = row
+            status[idx[0]] = st.value
+            continue
+        lengths = np.array([arrays[i].shape[0] for i in idx], np.uint64)  # frames
+        offsets = np.zeros(len(idx), np.uint64)
+        offsets[1:] = np.cumsum(lengths)[:-1]
+        pcm = np.concatenate([arrays[i].reshape(-1) for i in idx])
+        if pcm.size == 0:
+            pcm = np.zeros(1, np.int16 if s16 else np.float32)
+        res = np.empty((len(idx), d), np.float32)
+        st = np.empty(len(idx), np.int32)
+        _ffi.check(L.blissgpu_analyze_batch_interleaved(
+            pcm.ctypes.data, fmt, channels, offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+            lengths.ctypes.data_as(C.POINTER(C.c_uint64)), len(idx), int(version), res.ctypes.data,
+            st.ctypes.data_as(C.POINTER(C.c_int32))))
+        out[idx] = res
+        status[idx] = st
     results = []
     for i in range(n):
         if status[i] == _ffi.SONG_OK:

@@ -10,8 +10,13 @@
  * order [tempo, zcr, centroid mean/std, rolloff mean/std, flatness mean/std, loudness mean/std,
  * chroma x13|x10] (src/song/mod.rs:493-498, 102-156).
  *
- * Threading: a context is used by one host thread at a time (create one context per worker thread, as
- * bliss-rs creates one descriptor set per analyze call); different contexts are independent.
+ * Threading (src/song/decoder.rs:299-329: analyze is called from up to cores + 1 worker threads): EVERY entry point
+ * is re-entrant and thread-safe.  Each context carries a mutex; calls on one context are serialised (the host-pointer
+ * forms hold it for the whole call, the device forms while they enqueue), calls on different contexts run
+ * concurrently.  The entry points without a context argument share one process-wide context on device 0.
+ * Concurrent single-song calls (blissgpu_analyze / blissgpu_analyze_interleaved) are COALESCED: the calls that
+ * arrive while a batch is running are analysed together as the next device batch, so N worker threads each calling
+ * Song::analyze reach batch throughput without changing the caller.
  * The library has NO CPU fallback: every compute entry point fails with BLISSGPU_ERR_NO_DEVICE when no
  * gfx950 device / HIP runtime is usable.
  */
@@ -32,6 +37,7 @@ extern "C" {
 #define BLISSGPU_ERR_HIP 3            /* a HIP runtime call failed; see blissgpu_last_error() */
 #define BLISSGPU_ERR_OOM 4            /* workspace allocation failed */
 #define BLISSGPU_ERR_NAN 5            /* a distance is NaN: the reference panics there (n32(), argmin().unwrap()) */
+#define BLISSGPU_ERR_RCCL 6           /* librccl could not be loaded or a collective failed (blissgpu_node_* only) */
 
 /* ---- per-song status, maps 1:1 onto BlissError (src/lib.rs:236-252) ---- */
 #define BLISSGPU_SONG_OK 0
@@ -40,6 +46,10 @@ extern "C" {
 /* ---- FeaturesVersion (src/lib.rs:151-187) ---- */
 #define BLISSGPU_FEATURES_V1 1u       /* 20 features */
 #define BLISSGPU_FEATURES_V2 2u       /* 23 features (LATEST) */
+
+/* ---- sample formats of the PCM feed (decoder output before the mono f32 conversion) ---- */
+#define BLISSGPU_SAMPLE_F32 0
+#define BLISSGPU_SAMPLE_S16 1
 
 /* ---- distance metrics (src/playlist.rs:65-79, 129-142) ---- */
 #define BLISSGPU_METRIC_EUCLIDEAN 0
@@ -62,17 +72,28 @@ void *blissgpu_ctx_get_stream(blissgpu_ctx *ctx);
  * (results read there). */
 int blissgpu_ctx_wait_stream(blissgpu_ctx *ctx, void *producer_stream);
 int blissgpu_ctx_signal_stream(blissgpu_ctx *ctx, void *consumer_stream);
-/* Upper bound for the scratch workspace in bytes (default 96 GiB); larger batches run in chunks. */
+/* Upper bound in bytes for the scratch workspace of ONE chunk (there are two chunk slots; default: a third of the
+ * device memory free at creation, at most 64 GiB).  Larger batches are cut into length-bucketed chunks (longest songs
+ * first) that stream through the two slots: chunk k + 1's FFT kernels overlap chunk k's per-song tails.  A chunk that
+ * does not fit the memory actually free is halved and retried. */
 int blissgpu_ctx_set_workspace_limit(blissgpu_ctx *ctx, uint64_t bytes);
+uint64_t blissgpu_ctx_get_workspace_limit(blissgpu_ctx *ctx);
 int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
 
 uint32_t blissgpu_feature_count(uint32_t features_version); /* FeaturesVersion::feature_count, src/lib.rs:181-186 */
 
 /* Replaces Song::analyze / Song::analyze_with_options (src/song/mod.rs:403-508) for ONE song in host
  * memory.  Returns BLISSGPU_OK and writes feature_count floats, or BLISSGPU_OK with *status =
- * BLISSGPU_SONG_TOO_SHORT (out filled with NaN).  status may be NULL.  Uses a process-wide default
- * context on device 0. */
+ * BLISSGPU_SONG_TOO_SHORT (out filled with NaN).  status may be NULL.  Uses the process-wide default
+ * context on device 0; safe to call from any number of threads (concurrent calls are coalesced into one device batch). */
 int blissgpu_analyze(const float *pcm, uint64_t len, uint32_t features_version, float *out, int32_t *status);
+/* Same for raw decoder output: `frames` frames of `channels` interleaved samples (BLISSGPU_SAMPLE_F32 / _S16) at
+ * 22 050 Hz.  s16 is widened with sample / 32768 and channels are downmixed ON THE DEVICE exactly like the reference's
+ * decoders: stereo -> (L + R) * SQRT_2 / 2, more channels -> their mean (src/song/decoder/symphonia.rs:266-300; pinned
+ * on data/s16_stereo_22_5kHz.flac by Adler-32 0x1d7b2d6d, src/song/decoder/ffmpeg.rs:448-452).  Resampling is NOT
+ * done here: the caller delivers 22 050 Hz. */
+int blissgpu_analyze_interleaved(const void *pcm, int sample_format, uint32_t channels, uint64_t frames,
+                                 uint32_t features_version, float *out, int32_t *status);
 
 /* Bulk form: the compute half of Decoder::analyze_paths_with_options (src/song/decoder.rs:278-332) once the
  * decoders have produced PCM.  pcm holds the songs back to back (song i = pcm[offsets[i] ..
@@ -88,12 +109,21 @@ int blissgpu_analyze_batch(const float *pcm, const uint64_t *offsets, const uint
  * of the previous one. */
 int blissgpu_analyze_batch_s16(const int16_t *pcm, const uint64_t *offsets, const uint64_t *lengths, uint32_t n_songs,
                                uint32_t features_version, float *out, int32_t *status);
-/* The conversion alone, device to device (asynchronous on the context's stream). */
+/* Bulk form for interleaved multi-channel decoder output (see blissgpu_analyze_interleaved); offsets / lengths are in
+ * FRAMES. */
+int blissgpu_analyze_batch_interleaved(const void *pcm, int sample_format, uint32_t channels, const uint64_t *offsets,
+                                       const uint64_t *lengths, uint32_t n_songs, uint32_t features_version, float *out,
+                                       int32_t *status);
+/* The conversions alone, device to device (asynchronous on the context's stream). */
 int blissgpu_pcm_s16_to_f32_device(blissgpu_ctx *ctx, const int16_t *d_in, uint64_t n_samples, float *d_out);
+int blissgpu_pcm_downmix_device(blissgpu_ctx *ctx, const void *d_in, int sample_format, uint32_t channels, uint64_t frames,
+                                float *d_out);
 
 /* Device-resident form: d_pcm / d_out / d_status are HIP device pointers (d_status may be NULL),
  * offsets / lengths stay on the host (they size the launch).  Asynchronous on the context's
- * stream; call blissgpu_ctx_synchronize (or synchronise the stream) before reading d_out. */
+ * stream (d_status is written by the device too: no host synchronisation inside); call blissgpu_ctx_synchronize (or
+ * synchronise the stream) before reading d_out.  This is the streaming scheduler of configs like "50 000 songs of
+ * 30 s - 10 min": songs are bucketed by length and run as chunks through two workspace slots. */
 int blissgpu_analyze_batch_device(blissgpu_ctx *ctx, const float *d_pcm, const uint64_t *offsets,
                                   const uint64_t *lengths, uint32_t n_songs, uint32_t features_version,
                                   float *d_out, int32_t *d_status);
@@ -117,6 +147,9 @@ int blissgpu_pairwise_device(blissgpu_ctx *ctx, const float *d_A, uint64_t n, co
  * The metric built from a set of vectors is FunctionDistanceMetric (src/playlist.rs:36-59): the sequential
  * f32 sum over the set of func(vector_of_the_set, candidate), func = one of the three metrics above.
  * A NaN distance returns BLISSGPU_ERR_NAN (the reference panics: n32() / argmin().unwrap()). */
+
+/* n_seeds may be 0: the sum over an empty set is 0.0 for every candidate, so closest_to_songs returns the candidates
+ * in their own order and song_to_song starts from candidate 0. */
 
 /* FunctionDistanceMetric::distance for every candidate: out[j] = sum_i metric(seeds[i], cand[j]). */
 int blissgpu_set_distance(const float *seeds, uint32_t n_seeds, const float *cand, uint64_t n, uint32_t d, int metric,
@@ -142,6 +175,38 @@ int blissgpu_song_to_song_device(blissgpu_ctx *ctx, const float *d_seeds, uint32
 
 /* FeaturesVersion::feature_weights (src/lib.rs:168-173, 209-234): d x d row-major diagonal matrix. */
 int blissgpu_feature_weights(uint32_t features_version, float *M);
+
+/* ---- one process, every GPU of the node ----
+ * Songs are independent (Decoder::analyze_paths treats them so, src/song/decoder.rs:299-329), so a library shards by song:
+ * greedy longest-first balance of the samples per device, no data-path collective.  After the local batches ONE RCCL
+ * all-gather over xGMI (padded to the largest shard) leaves the full n x d feature matrix on every device; the pairwise
+ * kernel is then row-block sharded with no further exchange.  RCCL is loaded at run time; without it node creation
+ * fails with BLISSGPU_ERR_RCCL.  (bliss_rs_amd/shard.py is the one-process-per-GPU form of the same plan on
+ * torch.distributed.) */
+typedef struct blissgpu_node blissgpu_node;
+/* devices: HIP ordinals (NULL = 0 .. n_devices-1).  Creates one context per device and the RCCL communicators
+ * (ncclCommInitAll). */
+int blissgpu_node_create(int n_devices, const int *devices, blissgpu_node **node);
+int blissgpu_node_destroy(blissgpu_node *node);
+int blissgpu_node_device_count(blissgpu_node *node);
+blissgpu_ctx *blissgpu_node_ctx(blissgpu_node *node, int rank); /* the rank's context (device forms, synth, malloc) */
+/* The sharding plan: rank_of_song[i] = device rank that analyses song i. */
+int blissgpu_node_shard(blissgpu_node *node, const uint64_t *lengths, uint32_t n_songs, uint32_t *rank_of_song);
+/* Rows [lo, hi) of an n_rows-row distance matrix computed by `rank`. */
+void blissgpu_node_row_block(blissgpu_node *node, uint64_t n_rows, int rank, uint64_t *lo, uint64_t *hi);
+/* Bulk analysis of host PCM (the node form of blissgpu_analyze_batch): shards, feeds every device from its own host
+ * thread, gathers.  out (host, n_songs x feature_count) and status as in blissgpu_analyze_batch. */
+int blissgpu_node_analyze(blissgpu_node *node, const float *pcm, const uint64_t *offsets, const uint64_t *lengths,
+                          uint32_t n_songs, uint32_t features_version, float *out, int32_t *status);
+/* Device-resident form: song i lives on device rank_of_song[i] at d_pcm[rank_of_song[i]] + offsets[i].  Asynchronous. */
+int blissgpu_node_analyze_device(blissgpu_node *node, const float *const *d_pcm, const uint64_t *offsets,
+                                 const uint64_t *lengths, const uint32_t *rank_of_song, uint32_t n_songs,
+                                 uint32_t features_version);
+/* The gathered n_songs x feature_count matrix of the last analysis on `rank`'s device (valid after synchronize). */
+const float *blissgpu_node_features(blissgpu_node *node, int rank);
+/* All-pairs distances over the gathered matrix, rows sharded across the devices; out is host memory, n x n. */
+int blissgpu_node_pairwise(blissgpu_node *node, int metric, const float *M, float *out);
+int blissgpu_node_synchronize(blissgpu_node *node);
 
 /* ---- device memory helpers for hosts without their own HIP binding (Rust/C callers) ---- */
 int blissgpu_malloc(void **d_ptr, uint64_t bytes);
@@ -171,8 +236,12 @@ int blissgpu_profile_get(blissgpu_ctx *ctx, int kernel, double *total_ms, uint64
  * (src/chroma.rs:361-391); n_bpms[i] = number of beats BPMDesc recorded (src/temporal.rs:50-58). */
 int blissgpu_debug_last_tuning(blissgpu_ctx *ctx, double *tuning, uint32_t *n_bpms, uint32_t n_songs);
 
-/* Intermediate series of song `song` of the LAST chunk run on ctx (per-stage parity tests).  Copies at
- * most max_elems 4-byte elements to dst, reports the available count in *n_elems. */
+/* Number of chunks the last blissgpu_analyze_batch_device call on ctx was cut into. */
+uint64_t blissgpu_debug_last_chunks(blissgpu_ctx *ctx);
+
+/* Intermediate series of song `song` (the caller's index into the last batch; it must belong to the LAST chunk run
+ * on ctx) for the per-stage parity tests.  Copies at most max_elems 4-byte elements to dst, reports the available
+ * count in *n_elems. */
 #define BLISSGPU_DEBUG_CENTROID 0      /* f32[n_t]  per-frame spectral centroid in Hz (src/timbral.rs:159-173) */
 #define BLISSGPU_DEBUG_ROLLOFF 1       /* f32[n_t]  per-frame rolloff in Hz (:175-194) */
 #define BLISSGPU_DEBUG_FLATNESS 2      /* f32[n_t]  per-frame flatness (:196-208) */

@@ -42,6 +42,9 @@ NPY = [
 def main():
     for name in NPY:
         shutil.copyfile(os.path.join(DATA, name), os.path.join(HERE, name))
+    # a library file as an older bliss-rs wrote it: the DATA file its own upgrade test loads
+    # (src/library.rs:3935-4002, data/old_database.sql) -- rows + the old schema, no program text
+    shutil.copyfile(os.path.join(DATA, "old_database.sql"), os.path.join(HERE, "old_database.sql"))
 
     # golden song -> s16 PCM (exactly what ffmpeg hands the reference, before the /32768 scaling)
     a, sr, bps = decode_flac(os.path.join(DATA, "s16_mono_22_5kHz.flac"))

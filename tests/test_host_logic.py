@@ -97,13 +97,26 @@ def test_decoder_host_side(bliss, tmp_path):
     assert all(isinstance(r, bliss.DecodingError) for _, r in out)
     with pytest.raises(bliss.DecodingError):
         bliss.RawPcmDecoder.decode(str(tmp_path / "missing.wav"))
+    # stereo decoder output is passed on interleaved: the downmix runs on the device (blissgpu_analyze_interleaved)
     p = tmp_path / "stereo.npy"
     np.save(p, np.zeros((10, 2), np.float32))
+    pre = bliss.RawPcmDecoder.decode(str(p))
+    assert pre.sample_array.shape == (10, 2) and pre.duration == 10 / 22050
+    bad = tmp_path / "cube.npy"
+    np.save(bad, np.zeros((4, 2, 2), np.float32))
     with pytest.raises(bliss.DecodingError):
-        bliss.RawPcmDecoder.decode(str(p))
+        bliss.RawPcmDecoder.decode(str(bad))
+    # s16 stays s16 (2 bytes per sample over PCIe; widened on the device with sample / 32768)
     q = tmp_path / "s16.npy"
     np.save(q, np.array([16384, -32768], np.int16))
-    assert bliss.RawPcmDecoder.decode(str(q)).sample_array.tolist() == [0.5, -1.0]
+    got = bliss.RawPcmDecoder.decode(str(q)).sample_array
+    assert got.dtype == np.int16 and got.tolist() == [16384, -32768]
+    import wave
+    wv = tmp_path / "stereo.wav"
+    with wave.open(str(wv), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(22050)
+        f.writeframes(np.arange(8, dtype="<i2").tobytes())
+    assert bliss.RawPcmDecoder.decode(str(wv)).sample_array.tolist() == [[0, 1], [2, 3], [4, 5], [6, 7]]
 
 
 def test_flac_test_tool(golden_pcm):
