@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path named by BASELINE.json: songs/sec for batched 3-minute 22 050 Hz f32 analysis
-(all 23 features) on N MI355X, synthetic white-noise PCM resident in HBM, plus the HBM roofline of the
-dominant kernel, the CPU oracle timed beside it, and pairwise distances/sec over 100 k feature vectors.
+"""Benchmark of the hot path named by BASELINE.json: songs/sec for batched 22 050 Hz f32 analysis (all features) on
+N MI355X, synthetic white-noise PCM resident in HBM, with the HBM and FP32 rooflines, the CPU oracle timed beside it,
+and pairwise distances/sec over 100 k feature vectors.
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 1 --steps 3 --warmup 1                      # configs[1]: 1024 three-minute songs per GPU
+    python bench.py --config mixed                                     # configs[4]: this GPU's share of the 30 s - 10 min corpus
+    python bench.py --config library                                   # configs[2]: 10 000 songs, all-gather, sharded pairwise
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config ...]
 
-A "step" = one pass of Song::analyze over one batch of `--songs` (default 1024 = BASELINE configs[1])
-3-minute songs per GPU, followed (N > 1) by the RCCL all-gather of the feature rows.  Scaling is weak:
-per-GPU work is fixed.  Prints ONE JSON line on rank 0.
+A "step" = one pass of Song::analyze over this GPU's batch (+ the RCCL all-gather of the feature rows when N > 1;
+--config library adds the row-block-sharded pairwise kernel).  Prints ONE JSON line on rank 0.
+
+  config   workload                                                                       scaling
+  batch    configs[1]: --songs (1024) x 3 969 000-sample songs per GPU                     weak
+  mixed    configs[4]: 6 250 songs per GPU, durations uniform 30 s - 10 min (seeded),      weak (8 GPUs = the 50 000-song corpus)
+           sharded over the ranks by sample count, streamed through the chunk scheduler
+  library  configs[2]: 10 000 three-minute songs in total, 10 000 / N per GPU              strong
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,8 +30,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SONG_SAMPLES = 3969000  # 3 min at 22 050 Hz
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+SONG_SAMPLES = 3969000   # 3 min at 22 050 Hz
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP32_PEAK = 157.3e12     # MI355X FP32 vector peak, flop/s (same guide)
+# FP32-equivalent operation count of one analysis: 1.4e9 flop per 3-minute song with real-input
+# FFT counts (1800 FFT-8192 + 31 005 FFT-512 + the f64 chroma contraction + the beat tracker); it scales with the samples
+FLOP_PER_SAMPLE = 1.4e9 / SONG_SAMPLES
 
 
 def parse():
@@ -31,41 +43,90 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--songs", type=int, default=1024, help="3-minute songs per GPU per step")
-    ap.add_argument("--samples", type=int, default=SONG_SAMPLES, help="samples per song")
+    ap.add_argument("--config", choices=("batch", "mixed", "library"), default="batch")
+    ap.add_argument("--songs", type=int, default=0, help="songs per GPU per step (default: 1024 batch, 6250 mixed, 10000/N library)")
+    ap.add_argument("--samples", type=int, default=SONG_SAMPLES, help="samples per song (batch / library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pairwise", action="store_true")
     ap.add_argument("--pairwise-n", type=int, default=100000)
     ap.add_argument("--cpu-songs", type=int, default=128, help="songs timed on the CPU oracle (also the parity spot check)")
     ap.add_argument("--no-host-feed", action="store_true", help="skip the PCIe-inclusive host-buffer measurement")
     ap.add_argument("--no-playlist", action="store_true", help="skip the playlist-ordering measurement")
-    ap.add_argument("--ws-limit-gb", type=float, default=0.0, help="workspace limit (chunks the batch); 0 = library default")
+    ap.add_argument("--no-small-calls", action="store_true", help="skip the single-song latency / threaded small-call measurement")
+    ap.add_argument("--ws-limit-gb", type=float, default=0.0, help="workspace limit per chunk slot; 0 = library default")
     ap.add_argument("--host-feed-songs", type=int, default=256)
+    ap.add_argument("--seed", type=int, default=20260927)
     return ap.parse_args()
 
 
-def cpu_baseline(n_songs, samples, features_version=2):
-    """The oracle (C restatement of the reference algorithm, oracle/) on the host cores: the same
-    white-noise songs (bit-identical generator), one song per thread at a time.  The oracle is memory-bound well
-    before it runs out of cores (on the 2 x 64-core GPU host it peaks around 32 threads), so two thread counts are
-    timed and the better one is reported, with the thread count it used."""
+def mixed_lengths(n_total, seed):
+    """configs[4]: durations uniform in [30 s, 10 min] at 22 050 Hz, one seeded draw for the whole corpus"""
+    rng = np.random.default_rng(seed)
+    return rng.integers(30 * 22050, 600 * 22050 + 1, n_total).astype(np.uint64)
+
+
+def oracle_mod():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
 
+    return O
+
+
+def cpu_baseline(global_indices, lengths, features_version=2):
+    """The oracle (C restatement of the reference algorithm, oracle/) on the host cores: the same white-noise songs
+    (bit-identical generator), one song per thread at a time.  Two thread counts are timed (the port is memory-bound
+    well before it runs out of cores) and the better one is reported, with the thread count it used.  This is a PORT
+    (kind: "port"), not bliss-rs itself: see DESIGN.md section 5 for what that does and does not say."""
+    O = oracle_mod()
     ncpu = os.cpu_count() or 1
-    pcm = np.concatenate([O.white_noise(i, samples) for i in range(n_songs)])
-    offs = np.arange(n_songs, dtype=np.uint64) * np.uint64(samples)
-    lens = np.full(n_songs, samples, np.uint64)
-    tried = []
-    out = None
-    for cores in sorted({min(ncpu, n_songs, 32), min(ncpu, n_songs, 64)}):
+    n = len(global_indices)
+    pcm = np.concatenate([O.white_noise(int(g), int(l)) for g, l in zip(global_indices, lengths)])
+    lens = np.asarray(lengths, np.uint64)
+    offs = np.zeros(n, np.uint64)
+    offs[1:] = np.cumsum(lens)[:-1]
+    tried, out = [], None
+    for cores in sorted({min(ncpu, n, 32), min(ncpu, n, 64)}):
         t0 = time.perf_counter()
         out, status = O.song_analyze_batch(pcm, offs, lens, features_version, cores)
-        tried.append((n_songs / (time.perf_counter() - t0), cores))
+        tried.append((n / (time.perf_counter() - t0), cores))
     rate, cores = max(tried)
-    return {"value": round(rate, 3), "unit": "songs/sec", "cores": cores, "kind": "port",
-            "sample": f"{n_songs} of the same {samples}-sample white-noise songs, oracle/bliss_oracle.c; "
-                      + ", ".join(f"{c} threads: {r:.1f} songs/s" for r, c in tried) + f" ({ncpu} logical CPUs)"}, out
+    res = {"value": round(rate, 3), "unit": "songs/sec", "cores": cores, "kind": "port",
+           "sample": f"{n} of the same white-noise songs ({int(lens.sum())} samples), oracle/bliss_oracle.c (a port, not "
+                     "bliss-rs: its FFT is a plain radix-2, rustfft is SIMD mixed-radix); "
+                     + ", ".join(f"{c} threads: {r:.1f} songs/s" for r, c in tried) + f" ({ncpu} logical CPUs)",
+           "samples_per_sec": round(rate * float(lens.mean()), 1)}
+    try:  # per-descriptor seconds of ONE song on one core (SURVEY.md 8d): where the CPU time goes
+        k = int(np.argmin(np.abs(lens.astype(np.int64) - int(np.median(lens)))))
+        res["per_descriptor_seconds_one_song"] = O.song_analyze_timed(pcm[int(offs[k]):int(offs[k] + lens[k])], features_version)
+    except Exception as e:  # noqa: BLE001
+        res["per_descriptor_seconds_one_song"] = {"error": str(e)[:200]}
+    return res, out
+
+
+def small_calls():
+    """Single-song latency, 16-thread small-call throughput and ns per Song::distance through the host-pointer C ABI
+    (tests/cpp/test_threads.cpp: also the re-entrancy check)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "test_threads")
+    src = os.path.join(ROOT, "tests", "cpp", "test_threads.cpp")
+    libdir = os.path.join(ROOT, "bliss-rs_amd")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", src, "-o", exe, f"-L{libdir}", "-lblissgpu",
+                               f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([exe, "16", "32"], capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError((out.stdout + out.stderr)[-300:])
+    res = {}
+    for line in out.stdout.splitlines():
+        parts = line.split()
+        if len(parts) == 2:
+            try:
+                res[parts[0]] = float(parts[1])
+            except ValueError:
+                pass
+    res["note"] = ("blissgpu_analyze from 16 threads x 32 calls (3-22 s songs, pageable host memory): concurrent callers are "
+                   "coalesced into device batches; every row bit-identical to the serial run")
+    return res
 
 
 def main():
@@ -74,7 +135,7 @@ def main():
     import torch.distributed as dist
 
     import bliss_rs_amd as bliss
-    from bliss_rs_amd.shard import all_gather_features
+    from bliss_rs_amd.shard import all_gather_features, row_block, shard_songs
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -86,27 +147,88 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    n, N, d = args.songs, args.samples, 23
     ctx = bliss.Context(local_rank)
+    version = 2
+    scaling = "weak"
+    notes = {}
+    # ---- the workload: global song list -> this rank's share ----
+    if args.config == "batch":
+        n = args.songs or 1024
+        N = args.samples
+        lens = np.full(n, N, np.uint64)
+        global_idx = np.arange(rank * n, rank * n + n)
+        n_total = world * n
+        workload = (f"configs[1]: batch of {n} synthetic {N}-sample (3-min) white-noise f32 PCM buffers per GPU, full "
+                    f"23-feature descriptor set (FeaturesVersion 2)")
+    elif args.config == "library":
+        n_total = (args.songs * world) if args.songs else 10000
+        N = args.samples
+        version = 1  # BASELINE configs[2] gathers 20-dim feature vectors = FeaturesVersion 1
+        scaling = "strong"
+        shards = shard_songs(np.full(n_total, N, np.int64), world)
+        global_idx = shards[rank]
+        n = len(global_idx)
+        lens = np.full(n, N, np.uint64)
+        workload = (f"configs[2]: {n_total} pre-decoded {N}-sample (3-min) songs sharded across {world} GPU(s) "
+                    f"({n} on this rank), RCCL all-gather of the 20-dim feature rows (FeaturesVersion 1), then the "
+                    f"row-block-sharded {n_total} x {n_total} euclidean pairwise kernel on every rank")
+    else:  # mixed
+        per_gpu = args.songs or 6250
+        n_total = per_gpu * world
+        all_lens = mixed_lengths(n_total, args.seed)
+        shards = shard_songs(all_lens.astype(np.int64), world)
+        global_idx = shards[rank]
+        lens = all_lens[global_idx]
+        # everything must be resident before the timed region: trim the share to what fits beside two chunk slots
+        free_b, total_b = torch.cuda.mem_get_info()
+        slot_gb = args.ws_limit_gb if args.ws_limit_gb > 0 else 24.0
+        budget = free_b - int(2 * slot_gb * (1 << 30) * 1.15) - (6 << 30)
+        keep = int(np.searchsorted(np.cumsum((lens + 63) // 64 * 64 * 4), budget))
+        if keep < len(lens):
+            notes["trimmed"] = f"{len(lens)} -> {keep} songs: the PCM of the full share does not fit {free_b / 2**30:.0f} GiB free"
+            global_idx, lens = global_idx[:keep], lens[:keep]
+        n = len(global_idx)
+        if args.ws_limit_gb <= 0:
+            args.ws_limit_gb = slot_gb
+        workload = (f"configs[4]: mixed-duration corpus, {per_gpu} songs per GPU x {world} GPU(s) = {n_total} songs "
+                    f"(8 GPUs = the 50 000-song corpus), durations uniform 30 s - 10 min (seed {args.seed}), sharded by "
+                    f"sample count ({n} songs / {int(lens.sum())} samples on this rank), length-bucketed chunks streamed "
+                    f"through two {args.ws_limit_gb:g} GiB workspace slots, full 23-feature set")
+        N = int(lens.mean())
+    d = 23 if version == 2 else 20
     if args.ws_limit_gb > 0:
         ctx.set_workspace_limit(int(args.ws_limit_gb * (1 << 30)))
-    offs = np.arange(n, dtype=np.uint64) * np.uint64(N)
-    lens = np.full(n, N, np.uint64)
-    pcm = torch.empty(n * N, dtype=torch.float32, device="cuda")
-    ctx.synth_white_noise(pcm, offs, lens, first_song_index=rank * n)  # global song index = rank*n + i
+
+    padded = (lens + np.uint64(63)) // np.uint64(64) * np.uint64(64)
+    offs = np.zeros(n, np.uint64)
+    offs[1:] = np.cumsum(padded)[:-1]
+    total_samples = int(lens.sum())
+    pcm = torch.empty(int(padded.sum()) + 64, dtype=torch.float32, device="cuda")
+    # white noise written straight into HBM; song g of the corpus uses generator index g whatever the rank count
+    ctx.synth_white_noise(pcm, offs, lens, song_index=global_idx)
     out = torch.empty((n, d), dtype=torch.float32, device="cuda")
     status = torch.empty((n,), dtype=torch.int32, device="cuda")
-    global_idx = np.arange(rank * n, rank * n + n)
     global_idx_dev = torch.as_tensor(global_idx, device="cuda")  # uploaded once, not per step
+    n_local_max = max(len(s) for s in shards) if args.config != "batch" else n
+    D_block = None
+    if args.config == "library":
+        lo, hi = row_block(n_total, rank, world)
+        D_block = torch.empty((hi - lo, n_total), dtype=torch.float32, device="cuda")
 
     def step():
-        ctx.analyze(pcm, offs, lens, 2, out=out, status=status)
+        ctx.analyze(pcm, offs, lens, version, out=out, status=status)
+        full = out
         if world > 1:
-            return all_gather_features(out, global_idx_dev, world * n, n_local_max=n)
-        return out
+            full = all_gather_features(out, global_idx_dev, n_total, n_local_max=n_local_max)
+        if args.config == "library":
+            lo, hi = row_block(n_total, rank, world)
+            if world == 1:
+                ctx.pairwise(full, full, "euclidean", out=D_block)        # the whole matrix: symmetric kernel
+            else:
+                ctx.pairwise(full[lo:hi], full, "euclidean", out=D_block)  # this rank's row block, no exchange
+        return full
 
     def fence():
         torch.cuda.synchronize()
@@ -126,47 +248,64 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile()
     ctx.profile_enable(False)
+    chunks = ctx.last_chunks()
+    tot = torch.tensor([float(n), float(total_samples)], dtype=torch.float64, device="cuda")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total_songs = world * n * args.steps
-    value = total_songs / elapsed
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    job_songs, job_samples = float(tot[0].item()), float(tot[1].item())
+    value = job_songs * args.steps / elapsed
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: algorithmic bytes (4*N + 4*d per song,
-        # PCM read once + the feature row) x songs per launch / its average HIP-event duration ----
-        analysis_kernels = {k: v for k, v in prof.items() if k not in ("pairwise_kernel", "synth_kernel")}
+        # ---- HBM roofline of the dominant kernel: algorithmic bytes (4*N + 4*d per song, PCM read once
+        # + the feature row) of one launch / its average HIP-event duration (chunked runs: per chunk launch) ----
+        skip = ("pairwise_kernel", "synth_kernel", "set_distance_kernel", "song_to_song_kernel")
+        analysis_kernels = {k: v for k, v in prof.items() if k not in skip}
         dom = max(analysis_kernels, key=lambda k: analysis_kernels[k][0])
         dom_ms = analysis_kernels[dom][0] / analysis_kernels[dom][1]
-        algo_bytes = float(n) * (4.0 * N + 4.0 * d)
+        launches_per_step = analysis_kernels[dom][1] / args.steps
+        algo_bytes_step = 4.0 * total_samples + 4.0 * d * n
+        algo_bytes = algo_bytes_step / launches_per_step
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
+                    "avg_launch_ms": round(dom_ms, 4), "launches_per_step": launches_per_step,
+                    "algorithmic_bytes_per_launch": algo_bytes,
+                    "whole_step_GBps": round(algo_bytes_step / (elapsed / args.steps) / 1e9, 2),
                     "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
-                    "note": "the path is FP32-vector/LDS bound (~1.4 GFLOP per 15.9 MB song); see DESIGN.md"}
+                    "note": "by operation count the path is FP32-vector/LDS bound (roofline_fp32); see DESIGN.md section 3"}
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(traffic_file):
             try:
                 tf = json.load(open(traffic_file))
-                if tf.get("kernel") == dom and tf.get("songs_per_launch"):
-                    roofline["traffic"] = tf["bytes_per_launch"] * (n / tf["songs_per_launch"])
+                if tf.get("kernel") == dom and tf.get("bytes_per_sample"):
+                    roofline["traffic"] = tf["bytes_per_sample"] * total_samples / launches_per_step
+                elif tf.get("kernel") == dom and tf.get("songs_per_launch") and args.config != "mixed":
+                    roofline["traffic"] = tf["bytes_per_launch"] * (n / launches_per_step / tf["songs_per_launch"])
             except Exception:
                 pass
+        flops_step = FLOP_PER_SAMPLE * total_samples
+        fp32 = {"bound": "fp32-vector", "flops": flops_step, "achieved": round(flops_step / (elapsed / args.steps) / 1e12, 3),
+                "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": round(flops_step / (elapsed / args.steps) / FP32_PEAK, 5),
+                "note": "whole step on this GPU; 1.4e9 FP32-equivalent flop per 3-min song (real-input FFT counts), scaled by samples"}
 
         result = {
             "metric": "songs/sec (3-min 22 050 Hz f32) at 1/2/4/8 GPU; HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "songs/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic white noise (Philox4x32-10, uniform [-0.5,0.5)), generated in HBM",
-            "config": {"workload": f"configs[1]: batch of {n} synthetic {N}-sample (3-min) white-noise f32 PCM "
-                                   f"buffers per GPU, full 23-feature descriptor set (FeaturesVersion 2)",
-                       "songs_per_gpu": n, "samples_per_song": N, "features": d,
+            "config": {"workload": workload, "name": args.config, "songs_per_gpu": n, "songs_total": int(job_songs),
+                       "samples_per_song": N, "features": d, "chunks_per_step": int(chunks),
                        "parallelism": f"songs sharded x{world}, all-gather of feature rows" if world > 1 else "single GPU"},
-            "roofline": roofline,
+            "samples_per_sec": round(job_samples * args.steps / elapsed, 1),
+            "three_minute_song_equivalents_per_sec": round(job_samples * args.steps / elapsed / SONG_SAMPLES, 2),
+            "roofline": roofline, "roofline_fp32": fp32,
         }
+        result.update(notes)
 
         # The headline numbers above are complete at this point; the sections below are extras.  Each one is guarded so
         # that a failure there (a full host, no room for the 40 GB distance matrix, ...) is reported inside the JSON
@@ -179,9 +318,17 @@ def main():
 
         # ---- parity spot check inside the bench run + CPU baseline on the same songs ----
         def section_cpu_baseline():
-            cb, ref = cpu_baseline(min(args.cpu_songs, n), N)
-            got = out[: ref.shape[0]].cpu().numpy()
+            if args.config == "mixed":
+                # 16 songs spread evenly over the length buckets, shortest to longest (~80 min of audio: the oracle
+                # takes ~7 s per pass for the 10-minute song)
+                order = np.argsort(lens)
+                picks = sorted({int(order[int(q * (n - 1))]) for q in np.linspace(0.0, 1.0, 16)})
+            else:
+                picks = list(range(min(args.cpu_songs, n)))
+            cb, ref = cpu_baseline(global_idx[picks], lens[picks], version)
+            got = out[picks].cpu().numpy()
             err = np.abs(got - ref)
+            cb["checked_songs"] = len(picks)
             cb["max_abs_err_vs_gpu_non_tempo"] = float(err[:, 1:].max())
             cb["tempo_mismatches"] = int((err[:, 0] > 1e-4).sum())
             return cb
@@ -190,6 +337,17 @@ def main():
             guarded("cpu_baseline", section_cpu_baseline)
         elif not args.no_cpu_baseline:
             result["cpu_baseline"] = None
+
+        if args.config == "library":
+            pk = prof.get("pairwise_kernel")
+            if pk:
+                rows = D_block.shape[0]
+                kms = pk[0] / pk[1]
+                pbytes = 4.0 * rows * n_total + 4.0 * d * (rows + n_total)
+                result["pairwise_row_block"] = {"rows": rows, "cols": n_total, "kernel_ms": round(kms, 3),
+                                                "GBps": round(pbytes / (kms * 1e-3) / 1e9, 1)}
+
+        extras = args.config == "batch" and world == 1
 
         # ---- PCIe-inclusive rate of the host-buffer entry points (never `value`) ----
         def section_host_feed():
@@ -223,47 +381,55 @@ def main():
             feed["note"] = "blissgpu_analyze_batch[_s16] from host memory: H2D of one group pipelined with the analysis of the previous"
             return feed
 
-        if not args.no_host_feed and world == 1 and N >= 8192:
+        if extras and not args.no_host_feed and N == SONG_SAMPLES:
             guarded("host_feed", section_host_feed)
+
+        # ---- the per-call forms: latency, threaded small calls, Song::distance ----
+        if extras and not args.no_small_calls:
+            guarded("small_calls", small_calls)
 
         # ---- pairwise distances/sec over 100 k feature vectors (BASELINE configs[3]) ----
         def library_vectors():
             g = torch.Generator(device="cuda").manual_seed(1234)
-            return torch.rand((args.pairwise_n, d), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+            return torch.rand((args.pairwise_n, 23), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
 
         def section_pairwise():
             m = args.pairwise_n
             A = library_vectors()
+            B = A.clone()
             D = torch.empty((m, m), dtype=torch.float32, device="cuda")
-            ctx.pairwise(A, A, "euclidean", out=D)
-            torch.cuda.synchronize()
-            ctx.profile_enable(True)
-            ctx.profile_reset()
-            reps = 3
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                ctx.pairwise(A, A, "euclidean", out=D)
-            torch.cuda.synchronize()
-            dtp = (time.perf_counter() - t0) / reps
-            pms = ctx.profile()["pairwise_kernel"]
-            ctx.profile_enable(False)
-            kms = pms[0] / pms[1]
-            pbytes = 4.0 * m * m + 4.0 * d * 2 * m
-            return {"n": m, "d": d, "metric": "euclidean", "pairs_per_sec": round(m * m / dtp, 1),
-                    "ms": round(dtp * 1e3, 3), "kernel_ms": round(kms, 3),
-                    "note": "self-distance matrix of one library (A == B): upper block triangle computed, mirrored on store",
-                    "roofline": {"bound": "hbm", "achieved": round(pbytes / (kms * 1e-3) / 1e9, 1),
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(pbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+            res = {"n": m, "d": 23, "metric": "euclidean"}
+            for name, rhs in (("self", A), ("general", B)):
+                ctx.pairwise(A, rhs, "euclidean", out=D)
+                torch.cuda.synchronize()
+                ctx.profile_enable(True)
+                ctx.profile_reset()
+                reps = 3
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    ctx.pairwise(A, rhs, "euclidean", out=D)
+                torch.cuda.synchronize()
+                dtp = (time.perf_counter() - t0) / reps
+                pms = ctx.profile()["pairwise_kernel"]
+                ctx.profile_enable(False)
+                kms = pms[0] / pms[1]
+                pbytes = 4.0 * m * m + 4.0 * 23 * 2 * m
+                sec = {"pairs_per_sec": round(m * m / dtp, 1), "ms": round(dtp * 1e3, 3), "kernel_ms": round(kms, 3),
+                       "roofline": {"bound": "hbm", "achieved": round(pbytes / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": round(pbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+                if name == "self":
+                    res.update(sec)
+                    res["note"] = "self-distance matrix of one library (A == B): upper block triangle computed, mirrored on store"
+                else:
+                    res["general_A_ne_B"] = sec
+            return res
 
-        if not args.no_pairwise and world == 1:
+        if extras and not args.no_pairwise:
             guarded("pairwise", section_pairwise)
 
         # ---- playlist ordering over the same 100 k-vector library: closest_to_songs + song_to_song ----
         def section_playlist():
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle as O
-
+            O = oracle_mod()
             m = args.pairwise_n
             A = library_vectors()
             seeds = A[:3].clone()
@@ -286,7 +452,7 @@ def main():
             ref_chain = O.song_to_song(A_h[:1], A_h[:sub], "euclidean")
             t_chain_cpu = time.perf_counter() - t0
             return {
-                "n": m, "d": d,
+                "n": m, "d": 23,
                 "closest_to_songs_ms": round(t_sort * 1e3, 3), "closest_to_songs_matches_oracle": bool(np.array_equal(order.cpu().numpy(), ref_order)),
                 "closest_to_songs_cpu_ms": round(t_sort_cpu * 1e3, 1),
                 "song_to_song_s": round(t_chain, 3), "song_to_song_steps_per_sec": round(m / t_chain, 1),
@@ -296,7 +462,7 @@ def main():
                     ctx.song_to_song(A[:1], A[:sub], "euclidean").cpu().numpy(), ref_chain)),
             }
 
-        if not args.no_playlist and not args.no_pairwise and world == 1:
+        if extras and not args.no_playlist and not args.no_pairwise:
             guarded("playlist", section_playlist)
         print(json.dumps(result))
     if world > 1:

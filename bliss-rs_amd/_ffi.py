@@ -74,6 +74,7 @@ SIGNATURES = {
     "blissgpu_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     "blissgpu_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     "blissgpu_synth_white_noise_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, C.c_uint32]),
+    "blissgpu_synth_white_noise_indexed_device": (C.c_int, [_vp, _vp, _u64p, _u64p, _u32p, C.c_uint32]),
     "blissgpu_profile_enable": (C.c_int, [_vp, C.c_int]),
     "blissgpu_profile_reset": (C.c_int, [_vp]),
     "blissgpu_profile_kernel_count": (C.c_int, []),

@@ -220,7 +220,7 @@ int blissgpu_ctx_signal_stream(blissgpu_ctx* c, void* consumer_stream) {
 }
 
 int blissgpu_ctx_set_workspace_limit(blissgpu_ctx* c, uint64_t bytes) {
-    if (!c || bytes < (64ull << 20)) return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_set_workspace_limit", "limit < 64 MiB");
+    if (!c || bytes < (1ull << 20)) return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_set_workspace_limit", "limit < 1 MiB");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     c->ws_limit = bytes;
     return BLISSGPU_OK;
@@ -565,11 +565,11 @@ int blissgpu_memcpy_d2h(blissgpu_ctx* c, void* dst, const void* src, uint64_t by
     return BLISSGPU_OK;
 }
 
-int blissgpu_synth_white_noise_device(blissgpu_ctx* c, float* d_pcm, const uint64_t* offsets, const uint64_t* lengths,
-                                      uint32_t n_songs, uint32_t first_song_index) {
-    if (!c || !d_pcm || !offsets || !lengths) return fail(BLISSGPU_ERR_INVALID, "blissgpu_synth_white_noise_device", "NULL argument");
+static int synth_impl(blissgpu_ctx* c, float* d_pcm, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
+                      uint32_t first_song_index, const uint32_t* song_index) {
+    if (!c || !d_pcm || !offsets || !lengths) return fail(BLISSGPU_ERR_INVALID, "blissgpu_synth_white_noise", "NULL argument");
     if (n_songs == 0) return BLISSGPU_OK;
-    CTX_ENTER(c, "blissgpu_synth_white_noise_device");
+    CTX_ENTER(c, "blissgpu_synth_white_noise");
     std::vector<SongDesc> songs(n_songs);
     std::vector<uint32_t> pfx(n_songs + 1, 0);
     for (uint32_t i = 0; i < n_songs; i++) {
@@ -580,21 +580,35 @@ int blissgpu_synth_white_noise_device(blissgpu_ctx* c, float* d_pcm, const uint6
         pfx[i + 1] = pfx[i] + (uint32_t)((lengths[i] + 4095) / 4096);
     }
     SongDesc* d_songs = nullptr;
-    uint32_t* d_pfx = nullptr;
+    uint32_t *d_pfx = nullptr, *d_idx = nullptr;
     HIP_TRY(hipMalloc((void**)&d_songs, n_songs * sizeof(SongDesc)));
     hipError_t e = hipMalloc((void**)&d_pfx, (n_songs + 1) * sizeof(uint32_t));
+    if (e == hipSuccess && song_index) e = hipMalloc((void**)&d_idx, n_songs * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(d_songs, songs.data(), n_songs * sizeof(SongDesc), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_pfx, pfx.data(), (n_songs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && song_index) e = hipMemcpy(d_idx, song_index, n_songs * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         Prof p(c, K_SYNTH);
-        launch_synth(d_pcm, d_songs, n_songs, d_pfx, pfx[n_songs], first_song_index, c->stream);
+        launch_synth(d_pcm, d_songs, n_songs, d_pfx, pfx[n_songs], first_song_index, d_idx, c->stream);
     }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_songs);
     (void)hipFree(d_pfx);
+    (void)hipFree(d_idx);
     if (e != hipSuccess) return fail(BLISSGPU_ERR_HIP, "synth", hipGetErrorString(e));
     return BLISSGPU_OK;
+}
+
+int blissgpu_synth_white_noise_device(blissgpu_ctx* c, float* d_pcm, const uint64_t* offsets, const uint64_t* lengths,
+                                      uint32_t n_songs, uint32_t first_song_index) {
+    return synth_impl(c, d_pcm, offsets, lengths, n_songs, first_song_index, nullptr);
+}
+
+int blissgpu_synth_white_noise_indexed_device(blissgpu_ctx* c, float* d_pcm, const uint64_t* offsets, const uint64_t* lengths,
+                                              const uint32_t* song_index, uint32_t n_songs) {
+    if (!song_index) return fail(BLISSGPU_ERR_INVALID, "blissgpu_synth_white_noise_indexed_device", "NULL argument");
+    return synth_impl(c, d_pcm, offsets, lengths, n_songs, 0, song_index);
 }
 
 int blissgpu_profile_enable(blissgpu_ctx* c, int enable) {

@@ -177,6 +177,6 @@ void launch_song_to_song(const float* seeds, uint32_t n_seeds, const float* cand
 void launch_pairwise(const float* A, uint64_t n, const float* B, uint64_t m, uint32_t d, int metric, const float* M,
                      int m_is_diag, float* out, uint64_t ld_out, hipStream_t);
 void launch_synth(float* pcm, const SongDesc* songs, uint32_t n_songs, const uint32_t* pfx_e, uint32_t tiles_e,
-                  uint32_t first_song_index, hipStream_t);
+                  uint32_t first_song_index, const uint32_t* d_song_index, hipStream_t);
 
 }  // namespace bg

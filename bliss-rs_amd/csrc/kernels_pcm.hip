@@ -173,12 +173,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __global__ __launch_bounds__(256) void synth_kernel(float* __restrict__ pcm, const SongDesc* __restrict__ songs,
                                                     uint32_t n_songs, const uint32_t* __restrict__ pfx_e,
-                                                    uint32_t first_song_index) {
+                                                    uint32_t first_song_index, const uint32_t* __restrict__ song_index) {
     const uint32_t s = find_segment(pfx_e, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
     const uint32_t tile = blockIdx.x - pfx_e[s];
     float* __restrict__ x = pcm + sd.pcm_off;
-    const uint32_t k0 = 0x5EED0000u + first_song_index + s;
+    const uint32_t k0 = 0x5EED0000u + (song_index ? song_index[s] : first_song_index + s);
     // tile = 4096 samples = 1024 Philox blocks, 4 per thread
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -194,9 +194,9 @@ __global__ __launch_bounds__(256) void synth_kernel(float* __restrict__ pcm, con
 }
 
 void launch_synth(float* pcm, const SongDesc* songs, uint32_t n_songs, const uint32_t* pfx_e, uint32_t tiles_e,
-                  uint32_t first_song_index, hipStream_t st) {
+                  uint32_t first_song_index, const uint32_t* song_index, hipStream_t st) {
     if (tiles_e == 0) return;
-    hipLaunchKernelGGL(synth_kernel, dim3(tiles_e), dim3(256), 0, st, pcm, songs, n_songs, pfx_e, first_song_index);
+    hipLaunchKernelGGL(synth_kernel, dim3(tiles_e), dim3(256), 0, st, pcm, songs, n_songs, pfx_e, first_song_index, song_index);
 }
 
 }  // namespace bg

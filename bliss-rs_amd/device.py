@@ -90,12 +90,19 @@ class Context:
         self._post()
         return out, status
 
-    def synth_white_noise(self, pcm, offsets, lengths, first_song_index: int = 0):
+    def synth_white_noise(self, pcm, offsets, lengths, first_song_index: int = 0, song_index=None):
+        """Benchmark input: song i gets generator index first_song_index + i, or song_index[i] when given."""
         offsets, lengths = _u64(offsets), _u64(lengths)
         self._pre()
-        _ffi.check(self._L.blissgpu_synth_white_noise_device(
-            self._h, C.c_void_p(pcm.data_ptr()), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
-            lengths.ctypes.data_as(C.POINTER(C.c_uint64)), len(offsets), first_song_index))
+        if song_index is None:
+            _ffi.check(self._L.blissgpu_synth_white_noise_device(
+                self._h, C.c_void_p(pcm.data_ptr()), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                lengths.ctypes.data_as(C.POINTER(C.c_uint64)), len(offsets), first_song_index))
+        else:
+            idx = np.ascontiguousarray(song_index, np.uint32)
+            _ffi.check(self._L.blissgpu_synth_white_noise_indexed_device(
+                self._h, C.c_void_p(pcm.data_ptr()), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                lengths.ctypes.data_as(C.POINTER(C.c_uint64)), idx.ctypes.data_as(C.POINTER(C.c_uint32)), len(offsets)))
         self._post()
 
     def last_tuning(self, n):

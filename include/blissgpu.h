@@ -222,6 +222,9 @@ int blissgpu_host_free(void *h_ptr);
  * counter = sample_index / 4 (bit-identical to the oracle's generator).  No reference counterpart. */
 int blissgpu_synth_white_noise_device(blissgpu_ctx *ctx, float *d_pcm, const uint64_t *offsets,
                                       const uint64_t *lengths, uint32_t n_songs, uint32_t first_song_index);
+/* Same with an explicit generator index per song (a rank's scattered share of a sharded corpus). */
+int blissgpu_synth_white_noise_indexed_device(blissgpu_ctx *ctx, float *d_pcm, const uint64_t *offsets,
+                                              const uint64_t *lengths, const uint32_t *song_index, uint32_t n_songs);
 
 /* ---- per-kernel timing with HIP events on the context's stream (for bench.py's roofline) ---- */
 int blissgpu_profile_enable(blissgpu_ctx *ctx, int enable);

@@ -13,6 +13,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define PI_F 3.14159265358979323846f /* std::f32::consts::PI */
 
@@ -1091,6 +1092,42 @@ int bo_song_analyze(const float *x, size_t n, uint32_t features_version, float *
     out[8] = loud[0]; out[9] = loud[1];
     const int nch = features_version == 1 ? 10 : 13;
     for (int i = 0; i < nch; i++) out[10 + i] = ch[i];
+    return BO_OK;
+}
+
+/* The same analysis with a wall-clock timer around each descriptor (SURVEY.md 8d "where time goes today" on the CPU):
+ * secs[0..4] = tempo, timbral, zero-crossing rate, loudness, chroma.  Test / bench instrumentation, no reference
+ * counterpart; the feature row is the one bo_song_analyze returns. */
+static double now_seconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int bo_song_analyze_timed(const float *x, size_t n, uint32_t features_version, float *out, double secs[5]) {
+    if (features_version != 1 && features_version != 2) return BO_ERR_VERSION;
+    if (n < 8192) return BO_ERR_TOO_SHORT;
+    double t0 = now_seconds();
+    bo_bpm_desc *bpm = bo_bpm_desc_new(BO_SAMPLE_RATE);
+    for (size_t s = 0; s + 512 <= n; s += 256) bo_bpm_desc_do(bpm, x + s, 512);
+    out[0] = bo_bpm_desc_get_value(bpm);
+    bo_bpm_desc_free(bpm);
+    double t1 = now_seconds(); secs[0] = t1 - t0; t0 = t1;
+    bo_spectral_desc *sd = bo_spectral_desc_new(BO_SAMPLE_RATE);
+    for (size_t s = 0; s + 512 <= n; s += 128) bo_spectral_desc_do(sd, x + s);
+    bo_spectral_desc_get(sd, out + 2, out + 4, out + 6);
+    bo_spectral_desc_free(sd);
+    t1 = now_seconds(); secs[1] = t1 - t0; t0 = t1;
+    out[1] = bo_zcr(x, n);
+    t1 = now_seconds(); secs[2] = t1 - t0; t0 = t1;
+    bo_loudness(x, n, 0, out + 8);
+    t1 = now_seconds(); secs[3] = t1 - t0; t0 = t1;
+    size_t frames;
+    double *chroma = bo_chroma_desc_do(x, n, &frames, NULL);
+    if (features_version == 1) bo_chroma_get_values_v1(chroma, frames, out + 10);
+    else bo_chroma_get_values(chroma, frames, out + 10);
+    free(chroma);
+    secs[4] = now_seconds() - t0;
     return BO_OK;
 }
 

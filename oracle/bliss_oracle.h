@@ -88,6 +88,8 @@ float bo_zcr(const float *x, size_t n);                                     /* s
 #define BO_ERR_TOO_SHORT 1 /* AnalysisError("empty or too short song.") */
 #define BO_ERR_VERSION 2
 int bo_song_analyze(const float *x, size_t n, uint32_t features_version /* 1|2 */, float *out /* 20|23 */);
+/* same, with wall-clock seconds per descriptor: secs = {tempo, timbral, zcr, loudness, chroma} (instrumentation) */
+int bo_song_analyze_timed(const float *x, size_t n, uint32_t features_version, float *out, double secs[5]);
 /* analyse n_songs (ragged batch) on n_threads OS threads, songs dealt round-robin
  * (mirrors analyze_paths_with_options, src/song/decoder.rs:282-331) */
 void bo_song_analyze_batch(const float *pcm, const uint64_t *offsets, const uint64_t *lengths,

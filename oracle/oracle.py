@@ -66,6 +66,7 @@ def lib():
             "bo_loudness": (None, [f32p, sz, C.c_int, f32p]),
             "bo_zcr": (C.c_float, [f32p, sz]),
             "bo_song_analyze": (C.c_int, [f32p, sz, C.c_uint32, f32p]),
+            "bo_song_analyze_timed": (C.c_int, [f32p, sz, C.c_uint32, f32p, f64p]),
             "bo_song_analyze_batch": (None, [f32p, u64p, u64p, C.c_uint32, C.c_uint32, f32p, i32p, C.c_uint32]),
             "bo_euclidean_distance": (C.c_float, [f32p, f32p, sz]),
             "bo_cosine_distance": (C.c_float, [f32p, f32p, sz]),
@@ -343,6 +344,17 @@ def song_analyze(x, features_version=2):
     if rc != 0:
         raise ValueError(f"oracle error {rc}")
     return out
+
+
+def song_analyze_timed(x, features_version=2):
+    """-> {descriptor: seconds} of one analysis on one core (tempo, timbral, zcr, loudness, chroma)"""
+    x = _f32(x)
+    out = np.empty(23, np.float32)
+    secs = np.zeros(5, np.float64)
+    rc = lib().bo_song_analyze_timed(_p(x, C.c_float), len(x), features_version, _p(out, C.c_float), _p(secs, C.c_double))
+    if rc != 0:
+        raise ValueError(f"oracle error {rc}")
+    return {k: round(float(v), 4) for k, v in zip(("tempo", "timbral", "zcr", "loudness", "chroma"), secs)}
 
 
 def song_analyze_batch(pcm, offsets, lengths, features_version=2, n_threads=1):

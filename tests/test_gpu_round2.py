@@ -1,0 +1,319 @@
+"""GPU tests (-m gpu) of the boundary and scheduler work: re-entrancy of the C ABI, the coalescing single-song front,
+the two-slot streaming chunk schedule on a mixed-duration corpus (BASELINE configs[4] at reduced count), the pooled
+tuning candidates and their exact fallback, the device downmix (pinned by the reference's Adler-32), the node API over
+RCCL (n = 1 on the one-GPU box) and the edge cases the advisor listed (empty seed sets, a NaN that first appears at
+a later step of the greedy chain)."""
+import os
+import subprocess
+import sys
+import threading
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+
+FEATURE_TOL = 1e-5   # the reference's own tolerance (src/song/mod.rs:582-590)
+
+
+@pytest.fixture(scope="module")
+def bliss():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import bliss_rs_amd
+
+    return bliss_rs_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(bliss):
+    return bliss.Context(0)
+
+
+def _pack(songs):
+    lens = [len(s) for s in songs]
+    offs = np.concatenate([[0], np.cumsum([(l + 63) // 64 * 64 for l in lens])[:-1]]).astype(np.uint64)
+    buf = np.zeros(int(offs[-1]) + lens[-1] + 64, np.float32)
+    for s, o in zip(songs, offs):
+        buf[int(o):int(o) + len(s)] = s
+    return buf, offs, lens
+
+
+def _run(ctx, songs, version=2):
+    import torch
+
+    buf, offs, lens = _pack(songs)
+    out, status = ctx.analyze(torch.from_numpy(buf).cuda(), offs, lens, version)
+    ctx.synchronize()
+    return out.cpu().numpy(), status.cpu().numpy()
+
+
+def _mixed_corpus(oracle, n=40, seed=3):
+    """configs[4] in miniature: durations uniform in [3 s, 40 s] (the full config is 30 s - 10 min), one too-short song"""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(3 * 22050, 40 * 22050, n)
+    songs = [oracle.white_noise(500 + i, int(l)) for i, l in enumerate(lens)]
+    songs[7] = oracle.white_noise(507, 5000)  # too short
+    return songs
+
+
+# ---------------------------------------------------------------------------------------------
+# streaming scheduler: length-bucketed chunks through two workspace slots
+# ---------------------------------------------------------------------------------------------
+def test_streaming_chunks_match_single_chunk_and_oracle(bliss, oracle):
+    songs = _mixed_corpus(oracle)
+    one = bliss.Context(0)
+    ref, ref_st = _run(one, songs)
+    assert one.last_chunks() == 1
+    many = bliss.Context(0)
+    many.set_workspace_limit(8 << 20)       # ~ 40 s of audio per chunk (0.2 MB of scratch per second of audio)
+    got, st = _run(many, songs)
+    assert many.last_chunks() >= 12
+    assert st.tolist() == ref_st.tolist() and st[7] == 1 and st.sum() == 1
+    ok = st == 0
+    assert np.array_equal(got[ok], ref[ok]), "chunking must not change a single bit"
+    assert np.isnan(got[7]).all()
+    # a second batch on the same context reuses both slots (and their events) while the first may still be in flight
+    got2, _ = _run(many, songs[::-1])
+    assert np.array_equal(got2[::-1][ok], ref[ok])
+    # oracle spot check spread over the length buckets (shortest, quartiles, longest)
+    order = np.argsort([len(s) for s in songs])
+    picks = [int(order[k]) for k in (1, len(order) // 4, len(order) // 2, 3 * len(order) // 4, len(order) - 1)]
+    tempo_flips = 0
+    for i in picks:
+        want = oracle.song_analyze(songs[i], 2)
+        err = np.abs(got[i] - want)
+        n_t = (len(songs[i]) - 512) // 128 + 1
+        roll = 2.0 * (22050.0 / 512.0) / 11025.0 / n_t      # one rolloff frame flipping by one bin
+        tol = np.full(23, FEATURE_TOL)
+        tol[4] += 2 * roll
+        tol[5] += 2 * roll * np.sqrt(n_t) * 0.5
+        assert (err[1:] <= tol[1:]).all(), (i, err)
+        tempo_flips += int(err[0] > 1e-4)
+    assert tempo_flips == 0
+
+
+def test_debug_taps_follow_the_callers_song_index(ctx, oracle):
+    """chunks keep their songs in length order; the taps are addressed by the caller's index"""
+    songs = [oracle.white_noise(40, 9 * 22050), oracle.white_noise(41, 20 * 22050), oracle.white_noise(42, 14 * 22050)]
+    _run(ctx, songs)
+    for i, s in enumerate(songs):
+        zc = ctx.debug_fetch("crossings256", i)
+        assert zc.shape[0] == (len(s) + 255) // 256
+        assert int(zc.sum()) == oracle.number_crossings(s)
+
+
+# ---------------------------------------------------------------------------------------------
+# tuning candidates: pooled per chunk; a song the pool cannot serve re-scans its peak records
+# ---------------------------------------------------------------------------------------------
+def test_candidate_pool_exhaustion_takes_the_exact_path(bliss, oracle):
+    t = np.arange(12 * 22050) / 22050.0
+    songs = [
+        oracle.white_noise(60, 25 * 22050),
+        np.tile(np.concatenate([np.zeros(22000, np.float32), np.ones(100, np.float32)]), 20),   # clicks: flat spectra
+        (np.sin(2 * np.pi * 440.0 * t) * 0.3).astype(np.float32),
+        oracle.white_noise(61, 8192),
+    ]
+    base = bliss.Context(0)
+    ref, _ = _run(base, songs)
+    ref_tuning, _ = base.last_tuning(len(songs))
+    os.environ["BLISSGPU_CAND_BUDGET"] = "0"     # read at context creation: a 64-slot pool for the whole chunk
+    try:
+        starved = bliss.Context(0)
+    finally:
+        del os.environ["BLISSGPU_CAND_BUDGET"]
+    got, _ = _run(starved, songs)
+    tuning, _ = starved.last_tuning(len(songs))
+    assert np.array_equal(tuning, ref_tuning)
+    assert np.array_equal(got, ref)
+    for i, s in enumerate(songs):   # and both agree with the oracle's estimate_tuning
+        _, otuning = oracle.chroma_desc(s)
+        assert abs(tuning[i] - otuning) < 1e-12, (i, tuning[i], otuning)
+
+
+# ---------------------------------------------------------------------------------------------
+# re-entrancy: the reference calls Song::analyze from number_cores + 1 threads (src/song/decoder.rs:299-329)
+# ---------------------------------------------------------------------------------------------
+def test_c_abi_is_reentrant_16_threads_x_32_calls(tmp_path):
+    exe = tmp_path / "test_threads"
+    libdir = os.path.join(ROOT, "bliss-rs_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_threads.cpp"),
+                           "-o", str(exe), f"-L{libdir}", "-lblissgpu", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([str(exe), "16", "32"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all checks passed" in out.stdout
+    print(out.stdout)
+
+
+def test_python_threads_coalesce_and_stay_bit_identical(bliss, oracle):
+    songs = [oracle.white_noise(300 + i, (4 + i) * 22050 + 17 * i) for i in range(12)]
+    serial = [bliss.Song.analyze(s).as_arr1() for s in songs]
+    results = [[None] * len(songs) for _ in range(8)]
+
+    def worker(t):
+        for k in range(len(songs)):
+            i = (k + 3 * t) % len(songs)
+            results[t][i] = bliss.Song.analyze(songs[i]).as_arr1()   # ctypes releases the GIL inside the call
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for t in range(8):
+        for i in range(len(songs)):
+            assert np.array_equal(results[t][i], serial[i])
+    # the batch entry point and the single-song front agree bit for bit
+    batch = bliss.analyze_batch(songs)
+    for i in range(len(songs)):
+        assert np.array_equal(batch[i].as_arr1(), serial[i])
+
+
+def test_two_contexts_run_concurrently_from_two_threads(bliss, oracle):
+    songs = [oracle.white_noise(700 + i, 6 * 22050 + 1000 * i) for i in range(6)]
+    ref, _ = _run(bliss.Context(0), songs)
+    outs = [None, None]
+
+    def worker(k):
+        c = bliss.Context(0, use_torch_stream=False)
+        for _ in range(3):
+            outs[k], _ = _run(c, songs)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert np.array_equal(outs[0], ref) and np.array_equal(outs[1], ref)
+
+
+# ---------------------------------------------------------------------------------------------
+# PCM feed: mono downmix on the device, pinned by the reference's Adler-32
+# ---------------------------------------------------------------------------------------------
+def test_device_downmix_matches_the_reference_hash(bliss, ctx):
+    import torch
+
+    stereo = load_golden("s16_stereo_22_5kHz.pcm_s16.npy")          # [frames, 2] int16, data/s16_stereo_22_5kHz.flac
+    assert stereo.shape[1] == 2
+    mono = ctx.pcm_downmix(torch.from_numpy(stereo).cuda()).cpu().numpy()
+    # test_resample_stereo: src/song/decoder/ffmpeg.rs:448-452 (and symphonia.rs:594-610)
+    assert zlib.adler32(mono.astype("<f4").tobytes()) == 0x1D7B2D6D
+    # f32 interleaved input takes the same arithmetic
+    as_f32 = (stereo.astype(np.float32) / np.float32(32768.0))
+    mono2 = ctx.pcm_downmix(torch.from_numpy(as_f32).cuda()).cpu().numpy()
+    assert np.array_equal(mono, mono2)
+    # analysing the stereo decoder output == analysing the host-downmixed PCM, bit for bit, single and batch form
+    want = bliss.Song.analyze(mono).as_arr1()
+    assert np.array_equal(bliss.Song.analyze(stereo).as_arr1(), want)
+    assert np.array_equal(bliss.Song.analyze(as_f32).as_arr1(), want)
+    both = bliss.analyze_batch([stereo, stereo[: 30000]])
+    assert np.array_equal(both[0].as_arr1(), want)
+    assert np.array_equal(both[1].as_arr1(), bliss.Song.analyze(mono[:30000]).as_arr1())
+    # more than two channels: the channel mean (src/song/decoder/symphonia.rs:291-297)
+    rng = np.random.default_rng(5)
+    quad = rng.uniform(-0.5, 0.5, (20000, 4)).astype(np.float32)
+    acc = np.zeros(20000, np.float32)
+    for c in range(4):
+        acc = (acc + quad[:, c]).astype(np.float32)
+    assert np.array_equal(ctx.pcm_downmix(torch.from_numpy(quad).cuda()).cpu().numpy(), acc / np.float32(4.0))
+
+
+def test_raw_pcm_decoder_feeds_stereo_wav(bliss, tmp_path):
+    import wave
+
+    stereo = load_golden("s16_stereo_22_5kHz.pcm_s16.npy")
+    p = tmp_path / "stereo.wav"
+    with wave.open(str(p), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(22050)
+        f.writeframes(stereo.astype("<i2").tobytes())
+    song = bliss.RawPcmDecoder.song_from_path(str(p))
+    x = stereo.astype(np.float32) / np.float32(32768.0)
+    mono = ((x[:, 0] + x[:, 1]) * np.float32(np.sqrt(2.0))) / np.float32(2.0)
+    assert np.array_equal(song.analysis.as_arr1(), bliss.Song.analyze(mono).as_arr1())
+
+
+# ---------------------------------------------------------------------------------------------
+# node API: one process, RCCL inside the library (n = 1 here; the sharding plan is checked against shard.py)
+# ---------------------------------------------------------------------------------------------
+def test_node_api_single_device_equals_the_context_path(bliss, oracle):
+    from bliss_rs_amd.shard import row_block, shard_songs
+
+    songs = [oracle.white_noise(800 + i, (5 + 2 * i) * 22050 + 7 * i) for i in range(9)] + [oracle.white_noise(899, 100)]
+    buf, offs, lens = _pack(songs)
+    node = bliss.Node(1)
+    out, status = node.analyze(buf, offs, lens, 2)
+    ref, ref_st = _run(bliss.Context(0), songs)
+    assert status.tolist() == ref_st.tolist()
+    ok = ref_st == 0
+    assert np.array_equal(out[ok], ref[ok])
+    gathered = node.features(0)                      # went through ncclAllGather + the scatter kernel
+    assert np.array_equal(gathered[ok], ref[ok]) and np.isnan(gathered[~ok]).all()
+    good = np.flatnonzero(ok)
+    D = node.pairwise("euclidean")
+    want = bliss.playlist.pairwise_distances(ref[good], ref[good], "euclidean")
+    assert np.array_equal(D[np.ix_(good, good)], want)
+    # the plan is the one bliss_rs_amd.shard computes (the torch.distributed form)
+    lengths = np.random.default_rng(1).integers(661500, 13230000, 1000)
+    for world in (1,):
+        ranks = node.shard(lengths)
+        shards = shard_songs(lengths, world)
+        for r, s in enumerate(shards):
+            assert np.array_equal(np.flatnonzero(ranks == r), s)
+    assert node.row_block(100003, 0) == row_block(100003, 0, 1)
+    node.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# playlist edge cases
+# ---------------------------------------------------------------------------------------------
+def test_empty_seed_set(bliss, oracle):
+    rng = np.random.default_rng(9)
+    X = rng.uniform(-1, 1, (300, 23)).astype(np.float32)
+    none = np.zeros((0, 23), np.float32)
+    P = bliss.playlist
+    order, dist = P.closest_to_songs_order(none, X, "euclidean")
+    ref_order, ref_dist = oracle.closest_to_songs(none, X, "euclidean")
+    assert np.array_equal(order, ref_order) and np.array_equal(order, np.arange(300)) and (dist == 0).all()
+    assert np.array_equal(P.song_to_song_order(none, X, "euclidean"), oracle.song_to_song(none, X, "euclidean"))
+    assert (P.set_distances(none, X, "cosine") == 0).all()
+
+
+def test_song_to_song_nan_at_a_later_step_returns_instead_of_hanging(bliss):
+    """two candidates with +inf in the same dimension: inf - inf = NaN appears only once one of them is the current
+    song (step >= 1).  The exit must be taken by every workgroup at the same step; run in a child with a timeout so a
+    regression cannot take the suite down."""
+    code = r"""
+import numpy as np, sys
+sys.path[:0] = [%r]
+import bliss_rs_amd as bliss
+rng = np.random.default_rng(2)
+X = rng.uniform(-1, 1, (70000, 23)).astype(np.float32)
+X[12345, 3] = np.inf
+X[54321, 3] = np.inf
+try:
+    bliss.playlist.song_to_song_order(X[:1], X, "euclidean")
+except ValueError as e:
+    assert "NaN" in str(e)
+    print("nan reported")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "nan reported" in out.stdout, out.stdout + out.stderr
+
+
+def test_single_pair_distance_is_the_pairwise_value(bliss, oracle):
+    rng = np.random.default_rng(4)
+    for d in (23, 20, 7, 33):
+        a, b = rng.uniform(-1, 1, d).astype(np.float32), rng.uniform(-1, 1, d).astype(np.float32)
+        M = rng.uniform(0, 1, (d, d)).astype(np.float32)
+        M = (M @ M.T).astype(np.float32)
+        P = bliss.playlist
+        assert np.float32(P.euclidean_distance(a, b)) == np.float32(oracle.euclidean_distance(a, b))
+        assert np.float32(P.cosine_distance(a, b)) == np.float32(oracle.cosine_distance(a, b))
+        assert np.float32(P.mahalanobis_distance(a, b, M)) == np.float32(oracle.mahalanobis_distance(a, b, M))
+        # a different matrix right after: the staged copy must be refreshed
+        M2 = np.eye(d, dtype=np.float32) * np.float32(0.5)
+        assert np.float32(P.mahalanobis_distance(a, b, M2)) == np.float32(oracle.mahalanobis_distance(a, b, M2))
