@@ -24,8 +24,9 @@
 typedef struct {
     size_t n;
     unsigned log2n;
-    float *tw_re, *tw_im; /* n/2 twiddles exp(-2*pi*i*k/n) */
+    float *tw_re, *tw_im; /* twiddles exp(-2*pi*i*k/n), k < n (the parity path reads k < n/2) */
     uint32_t *rev;
+    float *sr, *si;       /* scratch of the baseline-only transform below */
 } bo_fft;
 
 static bo_fft *fft_new(size_t n) {
@@ -33,10 +34,12 @@ static bo_fft *fft_new(size_t n) {
     p->n = n;
     p->log2n = 0;
     while (((size_t)1 << p->log2n) < n) p->log2n++;
-    p->tw_re = (float *)malloc(sizeof(float) * (n / 2 + 1));
-    p->tw_im = (float *)malloc(sizeof(float) * (n / 2 + 1));
+    p->tw_re = (float *)malloc(sizeof(float) * (n + 1));
+    p->tw_im = (float *)malloc(sizeof(float) * (n + 1));
     p->rev = (uint32_t *)malloc(sizeof(uint32_t) * n);
-    for (size_t k = 0; k < n / 2; k++) {
+    p->sr = (float *)malloc(sizeof(float) * n);
+    p->si = (float *)malloc(sizeof(float) * n);
+    for (size_t k = 0; k < n; k++) {
         double a = -2.0 * M_PI * (double)k / (double)n;
         p->tw_re[k] = (float)cos(a);
         p->tw_im[k] = (float)sin(a);
@@ -55,6 +58,8 @@ static void fft_free(bo_fft *p) {
     free(p->tw_re);
     free(p->tw_im);
     free(p->rev);
+    free(p->sr);
+    free(p->si);
     free(p);
 }
 
@@ -85,10 +90,66 @@ static void fft_forward_f64(const bo_fft *p, float *re32, float *im32) {
     free(re); free(im);
 }
 
+#ifdef BO_BASELINE_FAST_FFT
+/* BASELINE-ONLY build (oracle/Makefile target `native`, -O3 -march=native): a Stockham autosort radix-4 transform whose
+ * inner loops are contiguous, so the compiler vectorises them -- a fairer stand-in for rustfft's SIMD mixed-radix
+ * kernels when the port is TIMED beside the GPU (bench.py cpu_baseline).  It rounds differently from the radix-2
+ * transform below, so it is never used for parity: the checker is always the default build. */
+static void fft_forward_fast(const bo_fft *p, float *re, float *im) {
+    const size_t n = p->n;
+    float *xr = re, *xi = im, *yr = p->sr, *yi = p->si;
+    size_t len = n, s = 1;
+    while (len >= 4) {
+        const size_t m = len / 4, ts = n / len;
+        for (size_t pp = 0; pp < m; pp++) {
+            const float w1r = p->tw_re[pp * ts], w1i = p->tw_im[pp * ts];
+            const float w2r = p->tw_re[2 * pp * ts], w2i = p->tw_im[2 * pp * ts];
+            const float w3r = p->tw_re[3 * pp * ts], w3i = p->tw_im[3 * pp * ts];
+            const float *ar = xr + s * pp, *ai = xi + s * pp, *br = ar + s * m, *bi = ai + s * m;
+            const float *cr = br + s * m, *ci = bi + s * m, *dr = cr + s * m, *di = ci + s * m;
+            float *o0r = yr + s * 4 * pp, *o0i = yi + s * 4 * pp;
+            for (size_t q = 0; q < s; q++) {
+                const float apcr = ar[q] + cr[q], apci = ai[q] + ci[q], amcr = ar[q] - cr[q], amci = ai[q] - ci[q];
+                const float bpdr = br[q] + dr[q], bpdi = bi[q] + di[q], bmdr = br[q] - dr[q], bmdi = bi[q] - di[q];
+                /* (-i) * (b - d) = (bmd.im, -bmd.re) */
+                const float t1r = amcr + bmdi, t1i = amci - bmdr, t3r = amcr - bmdi, t3i = amci + bmdr;
+                const float t2r = apcr - bpdr, t2i = apci - bpdi;
+                o0r[q] = apcr + bpdr;
+                o0i[q] = apci + bpdi;
+                o0r[q + s] = t1r * w1r - t1i * w1i;
+                o0i[q + s] = t1r * w1i + t1i * w1r;
+                o0r[q + 2 * s] = t2r * w2r - t2i * w2i;
+                o0i[q + 2 * s] = t2r * w2i + t2i * w2r;
+                o0r[q + 3 * s] = t3r * w3r - t3i * w3i;
+                o0i[q + 3 * s] = t3r * w3i + t3i * w3r;
+            }
+        }
+        float *t = xr; xr = yr; yr = t;
+        t = xi; xi = yi; yi = t;
+        len /= 4;
+        s *= 4;
+    }
+    if (len == 2) {
+        for (size_t q = 0; q < s; q++) {
+            const float ar = xr[q], ai = xi[q], br = xr[q + s], bi = xi[q + s];
+            yr[q] = ar + br; yi[q] = ai + bi;
+            yr[q + s] = ar - br; yi[q + s] = ai - bi;
+        }
+        float *t = xr; xr = yr; yr = t;
+        t = xi; xi = yi; yi = t;
+    }
+    if (xr != re) { memcpy(re, xr, sizeof(float) * n); memcpy(im, xi, sizeof(float) * n); }
+}
+#endif
+
 /* in-place forward FFT on separate re/im arrays */
 static void fft_forward(const bo_fft *p, float *re, float *im) {
     const size_t n = p->n;
     if (g_fft_double) { fft_forward_f64(p, re, im); return; }
+#ifdef BO_BASELINE_FAST_FFT
+    fft_forward_fast(p, re, im);
+    return;
+#endif
     for (size_t i = 0; i < n; i++) {
         size_t j = p->rev[i];
         if (j > i) {

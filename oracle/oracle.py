@@ -346,18 +346,42 @@ def song_analyze(x, features_version=2):
     return out
 
 
-def song_analyze_timed(x, features_version=2):
+def song_analyze_timed(x, features_version=2, fast=False):
     """-> {descriptor: seconds} of one analysis on one core (tempo, timbral, zcr, loudness, chroma)"""
     x = _f32(x)
     out = np.empty(23, np.float32)
     secs = np.zeros(5, np.float64)
-    rc = lib().bo_song_analyze_timed(_p(x, C.c_float), len(x), features_version, _p(out, C.c_float), _p(secs, C.c_double))
+    rc = (lib_fast() if fast else lib()).bo_song_analyze_timed(_p(x, C.c_float), len(x), features_version, _p(out, C.c_float), _p(secs, C.c_double))
     if rc != 0:
         raise ValueError(f"oracle error {rc}")
     return {k: round(float(v), 4) for k, v in zip(("tempo", "timbral", "zcr", "loudness", "chroma"), secs)}
 
 
-def song_analyze_batch(pcm, offsets, lengths, features_version=2, n_threads=1):
+_fast = None
+
+
+def lib_fast():
+    """BASELINE-ONLY build (oracle/Makefile `native`: -O3 -march=native, vectorisable radix-4 FFT), compiled on the
+    machine that times it.  Never the checker: parity always uses lib()."""
+    global _fast
+    if _fast is None:
+        so = os.path.join(_HERE, "_native", "libbliss_oracle_fast.so")
+        src = os.path.join(_HERE, "bliss_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])
+        L = C.CDLL(so)
+        L.bo_song_analyze_batch.restype = None
+        L.bo_song_analyze_batch.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32,
+                                            C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_uint32]
+        L.bo_song_analyze_timed.restype = C.c_int
+        L.bo_song_analyze_timed.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_uint32, C.POINTER(C.c_float),
+                                            C.POINTER(C.c_double)]
+        _fast = L
+    return _fast
+
+
+def song_analyze_batch(pcm, offsets, lengths, features_version=2, n_threads=1, fast=False):
+    """fast=True: the baseline-only build (timing); its rows differ from the checker's by FFT rounding."""
     pcm = _f32(pcm)
     offsets = np.ascontiguousarray(offsets, np.uint64)
     lengths = np.ascontiguousarray(lengths, np.uint64)
@@ -365,8 +389,8 @@ def song_analyze_batch(pcm, offsets, lengths, features_version=2, n_threads=1):
     d = 23 if features_version == 2 else 20
     out = np.empty((n, d), np.float32)
     status = np.empty(n, np.int32)
-    lib().bo_song_analyze_batch(_p(pcm, C.c_float), _p(offsets, C.c_uint64), _p(lengths, C.c_uint64), n,
-                                features_version, _p(out, C.c_float), _p(status, C.c_int32), n_threads)
+    (lib_fast() if fast else lib()).bo_song_analyze_batch(_p(pcm, C.c_float), _p(offsets, C.c_uint64), _p(lengths, C.c_uint64), n,
+                                                          features_version, _p(out, C.c_float), _p(status, C.c_int32), n_threads)
     return out, status
 
 
