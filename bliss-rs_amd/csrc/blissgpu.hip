@@ -19,7 +19,7 @@ namespace {
 thread_local std::string g_last_error;
 
 const char* const kKernelNames[K_COUNT] = {
-    "pcm_stats_kernel", "fft512_kernel",     "onset_kernel",      "beat_kernel",   "stft8192_kernel", "tune_select_kernel",
+    "fft512_kernel",     "onset_kernel",      "beat_kernel",   "stft8192_kernel", "tune_select_kernel",
     "tune_pass2_kernel", "tune_final_kernel", "chroma_kernel",     "summary_kernel", "assemble_kernel", "pairwise_kernel", "set_distance_kernel", "song_to_song_kernel", "synth_kernel"};
 }  // namespace
 
@@ -149,11 +149,17 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
     hipError_t se = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(BLISSGPU_ERR_HIP, "hipStreamCreate", hipGetErrorString(se)); }
     c->stream = c->own_stream;
-    se = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    // the side streams carry small latency-bound kernels: at high priority they get a CU slot as soon as one frees up
+    // instead of queueing behind the thousands of workgroups of an FFT kernel
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    se = hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio_greatest);
+    if (se == hipSuccess) se = hipStreamCreateWithPriority(&c->chr_stream, hipStreamNonBlocking, prio_greatest);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_interop, hipEventDisableTiming);
     if (se == hipSuccess) se = hipHostMalloc((void**)&c->h_scalar, 64, hipHostMallocDefault);
     if (se != hipSuccess) { blissgpu_ctx_destroy(c); return fail(BLISSGPU_ERR_HIP, "aux stream/events", hipGetErrorString(se)); }
     if (const char* e = getenv("BLISSGPU_SERIAL")) c->serial = (e[0] == '1');
+    if (const char* e = getenv("BLISSGPU_PIPELINE_CHUNKS")) c->pipeline_chunks = (uint32_t)std::min(64, std::max(1, atoi(e)));
     // developer / test aid: slots per chroma frame of the tuning-candidate pool (0 forces the re-scan path of tune_final_kernel)
     if (const char* e = getenv("BLISSGPU_CAND_BUDGET")) c->cand_budget = (uint32_t)std::max(0, atoi(e));
     // Scratch limit per chunk slot: a third of what is free now, at most 64 GiB (1024 three-minute songs need ~37 GB).  A
@@ -177,6 +183,7 @@ int blissgpu_ctx_destroy(blissgpu_ctx* c) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+        if (c->chr_stream) (void)hipStreamSynchronize(c->chr_stream);
         for (auto& v : c->events)
             for (auto& ev : v) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
         (void)hipFree(c->tw8192); (void)hipFree(c->tw512); (void)hipFree(c->hann8192); (void)hipFree(c->hannz512);
@@ -187,6 +194,7 @@ int blissgpu_ctx_destroy(blissgpu_ctx* c) {
         c->st_a.release(); c->st_b.release(); c->st_m.release(); c->st_dist.release(); c->st_out.release();
         if (c->h_scalar) (void)hipHostFree(c->h_scalar);
         if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+        if (c->chr_stream) (void)hipStreamDestroy(c->chr_stream);
         if (c->ev_interop) (void)hipEventDestroy(c->ev_interop);
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     }
@@ -621,6 +629,7 @@ int blissgpu_profile_reset(blissgpu_ctx* c) {
     CTX_ENTER(c, "blissgpu_profile_reset");
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->aux_stream);
+    (void)hipStreamSynchronize(c->chr_stream);
     for (auto& v : c->events) {
         for (auto& ev : v) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
         v.clear();
@@ -636,6 +645,7 @@ int blissgpu_profile_get(blissgpu_ctx* c, int k, double* total_ms, uint64_t* lau
     CTX_ENTER(c, "blissgpu_profile_get");
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->aux_stream));
+    HIP_TRY(hipStreamSynchronize(c->chr_stream));
     double tot = 0.0;
     for (auto& ev : c->events[k]) {
         float ms = 0.0f;

@@ -77,10 +77,13 @@ struct ChunkSlot {
     DevBuf<uint8_t> slab;        // workspace carved per chunk
     DevBuf<uint8_t> desc;        // SongDesc[] + tile prefix arrays
     PinnedBuf<uint8_t> h_desc;   // pinned staging of desc
-    hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_stft = nullptr, ev_chroma = nullptr;
+    hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_stft = nullptr, ev_tune = nullptr, ev_sum = nullptr, ev_chroma = nullptr;
     hipEvent_t ev_desc = nullptr;  // recorded on the main stream after the descriptor copy: the staging area is free
     hipEvent_t ev_free = nullptr;  // recorded on the aux stream after the row assembly: the slot is free
     bool used = false;
+    bool back_pending = false;   // front half enqueued, chroma contraction + row assembly still to come
+    Batch batch{};               // launch parameters of the chunk in flight (back half)
+    Workspace ws{};
 };
 
 // Persistent staging of the host-pointer entry points (the PCM feed): two device PCM buffers (+ raw s16 / multi-channel
@@ -103,6 +106,8 @@ struct blissgpu_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // FFT + chroma chain (the caller-visible stream)
     hipStream_t aux_stream = nullptr;  // per-song tails: PCM statistics, summaries, beat tracker, row assembly
+    hipStream_t chr_stream = nullptr;  // tuning estimate of a chunk, beside the next chunk's FFT kernels
+    uint32_t pipeline_chunks = 4;      // big batches are cut into at least this many chunks (BLISSGPU_PIPELINE_CHUNKS)
     hipEvent_t ev_interop = nullptr;
     bool serial = false;               // BLISSGPU_SERIAL=1: single stream (clean per-kernel timings)
     uint64_t ws_limit = 0;             // bytes per chunk slot (set from the free device memory at creation)
@@ -159,6 +164,8 @@ struct Prof {  // HIP events around one launch, on the stream the kernel is laun
         }
     }
 };
+
+constexpr size_t PIPELINE_MIN_CHUNK_BYTES = 512u << 20;  // a pipeline chunk below ~16 three-minute songs no longer fills the GPU
 
 int default_ctx(blissgpu_ctx** out);  // process-wide context on device 0 (created on first use)
 

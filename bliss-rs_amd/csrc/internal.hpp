@@ -78,8 +78,7 @@ struct DeviceTables {   // constant tables, built once per context
 };
 
 enum KernelId : int {
-    K_PCM_STATS = 0,
-    K_FFT512,
+    K_FFT512 = 0,
     K_ONSET,
     K_BEAT,
     K_STFT8192,
@@ -138,18 +137,16 @@ struct Batch {
     const SongDesc* songs;    // device
     uint32_t n_songs;
     // tile prefix arrays (device), n_songs+1 entries each
-    const uint32_t* pfx_e;    // pcm-stats tiles
     const uint32_t* pfx_f;    // fft512 tiles
     const uint32_t* pfx_c;    // STFT tiles (STFT_TILE chroma frames each)
     const uint32_t* pfx_ct;   // 64-frame chroma tiles (tuning pass 2 workgroups, chroma_part slots)
     const uint32_t* pfx_cw;   // chroma contraction workgroups (4 tiles of 64 frames each)
-    uint32_t tiles_e, tiles_f, tiles_c, tiles_ct, tiles_cw;
+    uint32_t tiles_f, tiles_c, tiles_ct, tiles_cw;
     uint64_t total_b;         // tempo frames in the batch
     uint32_t max_nb;          // longest song's tempo-frame count
     uint32_t max_nt;          // longest song's timbral-frame count
 };
 
-void launch_pcm_stats(const Batch&, const Workspace&, hipStream_t);
 void launch_fft512(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
 void launch_onset(const Batch&, const Workspace&, hipStream_t);
 void launch_beat(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);

@@ -20,6 +20,8 @@
 // frames so the previous tempo frame's magnitudes stay in registers (one halo FFT per group).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "device_utils.hpp"
 #include "fft_r16.hpp"
 #include "internal.hpp"
@@ -67,7 +69,6 @@ struct FrameMags {
     float nyq;    // |X[256]| (every lane)
 };
 
-// 257 magnitudes of FFT frame k: lane l of the group gets bins 16l..16l+15
 // constant tables staged once per workgroup in LDS (broadcast reads, no VMEM traffic per frame)
 struct Tables512 {
     f2 win[256];    // (hannz[2n], hannz[2n+1]), n = 16 n1 + l
@@ -75,14 +76,16 @@ struct Tables512 {
     f2 tw512[256];  // W_512^(16 l + e) at [16 e + l]: lane-contiguous (a [16 l + e] layout is a 16-way bank conflict)
 };
 
-// raw samples of one frame: row n1 of lane l = (x[s + 32 n1 + 2l], x[s + 32 n1 + 2l + 1]); samples before the song
-// start are 0 (the reference's zero-initialised sliding buffer); s is a multiple of 128, so pairs never straddle 0
-template <int ABL>
+// Raw sample rows of a lane group live in a ROTATING register window: row n1 of the frame with rotation R (= 4 x its
+// position in the unrolled loop body, mod 16) is raw[(R + n1) & 15].  Consecutive frames share 384 of their 512 samples,
+// so a frame only loads its four new rows over the four oldest ones -- no register moves.
+template <int R>
+__device__ __forceinline__ f2& row(f2 (&raw)[16], int n1) { return raw[(R + n1) & 15]; }
+
+// all 16 rows of one frame: row n1 of lane l = (x[s + 32 n1 + 2l], x[s + 32 n1 + 2l + 1]); samples before the song start
+// are 0 (the reference's zero-initialised sliding buffer); s is a multiple of 128, so pairs never straddle 0
 __device__ __forceinline__ void fft512_load(__amdgpu_buffer_rsrc_t r_x, long rel_start, int l, f2 (&raw)[16]) {
-    if (ABL == 3) {
-#pragma unroll
-        for (int n1 = 0; n1 < 16; n1++) raw[n1] = mk((float)(l + n1), 1.0f);
-    } else if (rel_start >= 0) {
+    if (rel_start >= 0) {
         const uint32_t xoff = (uint32_t)((rel_start + 2 * l) * 4);
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1++) raw[n1] = buf_load_f2(r_x, xoff, 128u * n1);
@@ -96,11 +99,12 @@ __device__ __forceinline__ void fft512_load(__amdgpu_buffer_rsrc_t r_x, long rel
     }
 }
 
-template <int ABL>
-__device__ __forceinline__ void fft512_compute(const f2 (&raw)[16], int l, f2* tile, const Tables512* tabs, FrameMags& out) {
+// 257 magnitudes of one frame: lane l of the group gets bins 16l..16l+15
+template <int R>
+__device__ __forceinline__ void fft512_compute(f2 (&raw)[16], int l, f2* tile, const Tables512* tabs, FrameMags& out) {
     f2 v[16];
 #pragma unroll
-    for (int n1 = 0; n1 < 16; n1++) v[n1] = raw[n1] * tabs->win[16 * n1 + l];
+    for (int n1 = 0; n1 < 16; n1++) v[n1] = row<R>(raw, n1) * tabs->win[16 * n1 + l];
     radix16(v);  // over n1 -> A[k1] at v[R16(k1)]
 #pragma unroll
     for (int k1 = 1; k1 < 16; k1++) v[R16(k1)] = cmul_pk(v[R16(k1)], tabs->tw256[16 * k1 + l]);  // W_256^(l*k1)
@@ -110,7 +114,7 @@ __device__ __forceinline__ void fft512_compute(const f2 (&raw)[16], int l, f2* t
 #pragma unroll
     for (int n2 = 0; n2 < 16; n2++) v[n2] = tile[l * 17 + n2];
     __builtin_amdgcn_wave_barrier();
-    if (ABL != 4) radix16(v);  // over n2 -> Z[l + 16 k2] at v[R16(k2)]
+    radix16(v);  // over n2 -> Z[l + 16 k2] at v[R16(k2)]
 #pragma unroll
     for (int k2 = 0; k2 < 16; k2++) tile[k2 * 17 + l] = v[R16(k2)];  // Z[k] at k + (k >> 4)
     __builtin_amdgcn_wave_barrier();
@@ -121,11 +125,7 @@ __device__ __forceinline__ void fft512_compute(const f2 (&raw)[16], int l, f2* t
         // Z[256 - k], k = 16 l + e  (k = 0 pairs with itself)
         const int mi = (e == 0) ? ((l == 0) ? 0 : 17 * (16 - l)) : (17 * (15 - l) + 16 - e);
         const f2 zm = tile[mi];
-        if (ABL == 2) out.m[e] = zk.x + zm.y;
-        else if (ABL == 5) out.m[e] = 0.5f * split_one_sq(zk, zm, tabs->tw512[16 * e + l]);
-        else if (ABL == 6) out.m[e] = mag_from_sq(split_one_sq(zk, zm, mk(0.6f, 0.8f)));
-        else if (ABL == 7) out.m[e] = mag_from_sq(split_one_sq(zk, zk, tabs->tw512[16 * e + l]));
-        else out.m[e] = mag_from_sq(split_one_sq(zk, zm, tabs->tw512[16 * e + l]));  // W_512^k, k = 16 l + e
+        out.m[e] = mag_from_sq(split_one_sq(zk, zm, tabs->tw512[16 * e + l]));  // W_512^k, k = 16 l + e
     }
     // Z is halved (half window): X[0] = 2 (Re Z[0] + Im Z[0]), X[256] = 2 (Re Z[0] - Im Z[0])
     if (l == 0) out.m[0] = 2.0f * fabsf(z0.x + z0.y);
@@ -133,14 +133,34 @@ __device__ __forceinline__ void fft512_compute(const f2 (&raw)[16], int l, f2* t
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int ABL>  // ABL != 0: timing ablations (developer aid, BLISSGPU_ABL512), results are wrong
+// ---- statistics of the PCM itself, folded into this kernel because it is the one that already holds every sample in
+// registers: per 256-sample block the sum of squares (LoudnessDesc, src/misc.rs:12-18,46-65, and the tempo silence test,
+// src/aubio.rs:1258-1276) and the zero-crossing count (number_crossings, src/utils.rs:81-95: a crossing is a change of
+// `x > 0` between consecutive samples; the first sample of the song compares with itself).  FFT frame k brings in the
+// 128 samples [128 k, 128 k + 128) = rows 12..15 of its window; `before` is row 11, whose last sample precedes them. ----
+constexpr int DPP_ROW_ROR1 = 0x121;
+__device__ __forceinline__ void stats128(const f2 r0, const f2 r1, const f2 r2, const f2 r3, const f2 before, bool song_start,
+                                         int l, float& ss, uint32_t& zc) {
+    ss += ((r0.x * r0.x + r0.y * r0.y) + (r1.x * r1.x + r1.y * r1.y)) + ((r2.x * r2.x + r2.y * r2.y) + (r3.x * r3.x + r3.y * r3.y));
+    const int x0 = r0.x > 0.0f, y0 = r0.y > 0.0f, x1 = r1.x > 0.0f, y1 = r1.y > 0.0f;
+    const int x2 = r2.x > 0.0f, y2 = r2.y > 0.0f, x3 = r3.x > 0.0f, y3 = r3.y > 0.0f;
+    const int yb = before.y > 0.0f;
+    // the sample before a lane's .x: the previous lane's .y of the same row; lane 0 takes lane 15 of the row before
+    const int a0 = dpp_mov<DPP_ROW_ROR1>(y0), a1 = dpp_mov<DPP_ROW_ROR1>(y1), a2 = dpp_mov<DPP_ROW_ROR1>(y2);
+    const int a3 = dpp_mov<DPP_ROW_ROR1>(y3), ab = dpp_mov<DPP_ROW_ROR1>(yb);
+    const bool first = l == 0;
+    const int p0 = first ? (song_start ? x0 : ab) : a0, p1 = first ? a0 : a1, p2 = first ? a1 : a2, p3 = first ? a2 : a3;
+    zc += (uint32_t)(((x0 ^ p0) + (y0 ^ x0)) + ((x1 ^ p1) + (y1 ^ x1)) + ((x2 ^ p2) + (y2 ^ x2)) + ((x3 ^ p3) + (y3 ^ x3)));
+}
+
 __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict__ pcm,
                                                         const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                         const uint32_t* __restrict__ pfx_f,
                                                         const float* __restrict__ hannz,
                                                         const float2* __restrict__ tw512,
                                                         float* __restrict__ centroid, float* __restrict__ rolloff,
-                                                        float* __restrict__ flatness, float* __restrict__ flux) {
+                                                        float* __restrict__ flatness, float* __restrict__ flux,
+                                                        float* __restrict__ e256, uint32_t* __restrict__ zc256) {
     __shared__ f2 lds[GROUPS_PER_WG * GRP_PITCH];
     __shared__ Tables512 tabs_s;
     {
@@ -158,7 +178,7 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
     f2* tile = lds + grp * GRP_PITCH;
 
-    const long k_begin = (long)tile_idx * F512_TILE + (long)grp * FRAMES_PER_GROUP;  // even
+    const long k_begin = (long)tile_idx * F512_TILE + (long)grp * FRAMES_PER_GROUP;  // a multiple of 32
     const long k_end = (k_begin + FRAMES_PER_GROUP < (long)sd.n_f) ? k_begin + FRAMES_PER_GROUP : (long)sd.n_f;
 
     // descriptor over this workgroup's slice of the song (keeps lane offsets 32-bit for any song length);
@@ -169,64 +189,75 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
     const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(pcm + sd.pcm_off + base), 0, (uint32_t)(avail < 0xFFFFFFFFull ? avail : 0xFFFFFFFFull), 0x00020000);
 
-    FrameMags cur, prev;
+    // Two magnitude sets alternate so that "the previous tempo frame" is never copied: over four frames k0 .. k0 + 3
+    // (k0 a multiple of 4) the previous odd frame lives in A, frames k0 and k0 + 1 are computed into B (the flux of
+    // k0 + 1 is B against A), frames k0 + 2 and k0 + 3 into A (flux: A against B).
+    FrameMags A, B;
     const bool active = k_begin < (long)sd.n_f;
-    // halo: magnitudes of the previous tempo frame (FFT frame k_begin - 1); zeros before the song starts
     f2 raw[16];
+    // halo: magnitudes of the previous tempo frame (FFT frame k_begin - 1); zeros before the song starts
     if (active && k_begin >= 1) {
-        fft512_load<ABL>(r_x, k_begin * HOP_T - W512 - base, l, raw);
-        fft512_compute<ABL>(raw, l, tile, tabs, prev);
+        fft512_load(r_x, k_begin * HOP_T - W512 - base, l, raw);
+        fft512_compute<0>(raw, l, tile, tabs, A);
     } else {
 #pragma unroll
-        for (int e = 0; e < 16; e++) prev.m[e] = 0.0f;
-        prev.nyq = 0.0f;
+        for (int e = 0; e < 16; e++) A.m[e] = 0.0f;
+        A.nyq = 0.0f;
     }
+    if (active) fft512_load(r_x, (k_begin + 1) * HOP_T - W512 - base, l, raw);
 
-    // Consecutive frames share 384 of their 512 samples: the raw rows stay in registers, every frame shifts them by
-    // four rows and loads only the four new ones -- issued a whole frame ahead, so their latency is off the critical path.
-    if (active) fft512_load<ABL>(r_x, (k_begin + 1) * HOP_T - W512 - base, l, raw);
-    for (long k = k_begin; k < k_end; k++) {
-        fft512_compute<ABL>(raw, l, tile, tabs, cur);
+    float ss_acc = 0.0f;    // per-lane partial sums of the current 256-sample block
+    uint32_t zc_acc = 0;
+    const float freq_per_bin = (float)SAMPLE_RATE / (float)W512;
+
+    // one frame of the unrolled body: J = position in the body (k = kb + J), CUR / PREV = the magnitude sets as above
+    auto frame = [&](auto jc, long k, FrameMags& cur, FrameMags& prev) {
+        constexpr int J = decltype(jc)::value;
+        constexpr int R = (4 * J) & 15;
+        stats128(row<R>(raw, 12), row<R>(raw, 13), row<R>(raw, 14), row<R>(raw, 15), row<R>(raw, 11), k == 0, l, ss_acc, zc_acc);
+        __builtin_amdgcn_sched_barrier(0);
+        fft512_compute<R>(raw, l, tile, tabs, cur);
         if (k + 1 < k_end) {
-#pragma unroll
-            for (int n1 = 0; n1 < 12; n1++) raw[n1] = raw[n1 + 4];
-            // rows 12..15 of frame k + 1 = samples [(k + 2) * 128 - 128, (k + 2) * 128): never before the song start
-            // (the lane offset addresses row 12 itself: a negative frame start must not wrap the 32-bit lane offset,
-            // the descriptor's range check does not see the scalar offset)
+            // rows 12..15 of frame k + 1 = samples [(k + 1) * 128, (k + 2) * 128) replace this frame's rows 0..3; issued a
+            // whole frame ahead, so their latency is off the critical path.  (The lane offset addresses the row itself: a
+            // negative frame start must not wrap the 32-bit lane offset, the descriptor's range check does not see the
+            // scalar offset.)
             const uint32_t xoff = (uint32_t)(((k + 2) * HOP_T - HOP_T - base + 2 * l) * 4);
 #pragma unroll
-            for (int n1 = 12; n1 < 16; n1++) raw[n1] = (ABL == 3) ? mk((float)(l + n1), 1.0f) : buf_load_f2(r_x, xoff, 128u * (n1 - 12));
+            for (int n1 = 0; n1 < 4; n1++) row<R>(raw, n1) = buf_load_f2(r_x, xoff, 128u * n1);
         }
-
-        if (k & 1) {  // tempo frame j = (k-1)/2 : SpecFlux over bins 0..256
+        if (J & 1) {
+            // 256-sample block q = (k - 1) / 2 is complete: reduce over the 16 lanes, lane 0 writes
+            const float ss = row16_sum(ss_acc);
+            const uint32_t zc = (uint32_t)row16_sum((int)zc_acc);
+            const long q = (k - 1) >> 1;
+            if (l == 0) { e256[sd.e_off + q] = ss; zc256[sd.e_off + q] = zc; }
+            ss_acc = 0.0f;
+            zc_acc = 0;
+            // tempo frame j = (k-1)/2 : SpecFlux over bins 0..256 (src/aubio.rs:455-467)
             float f = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
+            for (int e = 0; e < 16; e++)
                 if (cur.m[e] > prev.m[e]) f += cur.m[e] - prev.m[e];
-                prev.m[e] = cur.m[e];
-            }
             if (l == 0 && cur.nyq > prev.nyq) f += cur.nyq - prev.nyq;
-            prev.nyq = cur.nyq;
             f = row16_sum(f);
-            const long j = (k - 1) >> 1;
-            if (l == 0 && j < (long)sd.n_b) flux[sd.b_off + j] = f;
+            if (l == 0 && q < (long)sd.n_b) flux[sd.b_off + q] = f;
         }
-
-        if (ABL != 1 && k < (long)sd.n_t) {
-            // the 256-bin vector the reference's timbral path sees: bin 255 := |Re X[256]|
-            if (l == 15) cur.m[15] = cur.nyq;
+        if (k < (long)sd.n_t) {
+            // the 256-bin vector the reference's timbral path sees: bin 255 := |Re X[256]| (src/aubio.rs:240-261)
+            const float m15 = (l == 15) ? cur.nyq : cur.m[15];
             float sum = 0.0f, wsum = 0.0f, sqsum = 0.0f;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                sum += cur.m[e];
-                wsum += (float)(16 * l + e) * cur.m[e];
-                sqsum += cur.m[e] * cur.m[e];
+                const float me = e == 15 ? m15 : cur.m[e];
+                sum += me;
+                wsum += (float)(16 * l + e) * me;
+                sqsum += me * me;
             }
             const float total = row16_sum(sum);
             const float wtotal = row16_sum(wsum);
             // spectral_centroid (src/aubio.rs:16-29) then bin_to_freq (:68-71)
             const float cbin = (total == 0.0f) ? 0.0f : wtotal / total;
-            const float freq_per_bin = (float)SAMPLE_RATE / (float)W512;
             // spectral_rolloff (src/aubio.rs:36-58): bins consumed until the running energy reaches 95 %
             const float incl = row16_scan_incl(sqsum);
             const float cum_total = row16_sum(sqsum);
@@ -237,7 +268,8 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
                 int below = 0;
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
-                    run += cur.m[e] * cur.m[e];
+                    const float me = e == 15 ? m15 : cur.m[e];
+                    run += me * me;
                     below += (run < thr) ? 1 : 0;
                 }
                 const int c = row16_sum(below);
@@ -248,10 +280,11 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
             double mant = 1.0;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
+                const float c7 = h == 1 ? m15 : cur.m[7];
                 const float* c8 = cur.m + 8 * h;
                 double g = ((double)c8[0] * (double)c8[1]) * ((double)c8[2] * (double)c8[3]);
                 g *= 3.273390607896142e150;
-                g *= ((double)c8[4] * (double)c8[5]) * ((double)c8[6] * (double)c8[7]);
+                g *= ((double)c8[4] * (double)c8[5]) * ((double)c8[6] * (double)c7);
                 if (g == 0.0) zero = 1;
                 const uint64_t bits = (uint64_t)__double_as_longlong(g);
                 expo += (int)(bits >> 52);
@@ -272,23 +305,44 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
                 flatness[sd.t_off + k] = flat;
             }
         }
+    };
+
+    for (long kb = k_begin; kb < k_end; kb += 4) {
+        frame(std::integral_constant<int, 0>{}, kb, B, A);
+        __builtin_amdgcn_sched_barrier(0);  // keep the frames apart: interleaving two of them costs more registers than it hides
+        if (kb + 1 < k_end) frame(std::integral_constant<int, 1>{}, kb + 1, B, A);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 2 < k_end) frame(std::integral_constant<int, 2>{}, kb + 2, A, B);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 3 < k_end) frame(std::integral_constant<int, 3>{}, kb + 3, A, B);
+    }
+
+    // ---- the samples no FFT frame brings in: [128 n_f, n), 256 .. 511 of them, handled by the group that owns the
+    // song's last frame.  If n_f is odd the first of these blocks already holds the partial sums of frame n_f - 1. ----
+    if (active && k_end == (long)sd.n_f) {
+        const float* __restrict__ x = pcm + sd.pcm_off;
+        const uint64_t t0 = (uint64_t)sd.n_f * HOP_T;
+        for (uint64_t q = t0 >> 8; q < (uint64_t)sd.n_e; q++) {
+            const uint64_t lo = (q << 8) > t0 ? (q << 8) : t0;
+            const uint64_t hi = ((q + 1) << 8) < sd.n ? ((q + 1) << 8) : sd.n;
+            for (uint64_t i = lo + (uint64_t)l; i < hi; i += 16) {
+                const float v = x[i], pv = x[i - 1];  // i >= 128: a predecessor always exists
+                ss_acc += v * v;
+                zc_acc += ((v > 0.0f) != (pv > 0.0f)) ? 1u : 0u;
+            }
+            const float ss = row16_sum(ss_acc);
+            const uint32_t zc = (uint32_t)row16_sum((int)zc_acc);
+            if (l == 0) { e256[sd.e_off + q] = ss; zc256[sd.e_off + q] = zc; }
+            ss_acc = 0.0f;
+            zc_acc = 0;
+        }
     }
 }
 
 void launch_fft512(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.tiles_f == 0) return;
-    static const int abl = getenv("BLISSGPU_ABL512") ? atoi(getenv("BLISSGPU_ABL512")) : 0;
-#define LAUNCH_F512(A) hipLaunchKernelGGL(fft512_kernel<A>, dim3(b.tiles_f), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, \
-                                          b.pfx_f, t.hannz512, t.tw512, w.centroid, w.rolloff, w.flatness, w.flux)
-    if (abl == 1) LAUNCH_F512(1);
-    else if (abl == 2) LAUNCH_F512(2);
-    else if (abl == 3) LAUNCH_F512(3);
-    else if (abl == 4) LAUNCH_F512(4);
-    else if (abl == 5) LAUNCH_F512(5);
-    else if (abl == 6) LAUNCH_F512(6);
-    else if (abl == 7) LAUNCH_F512(7);
-    else LAUNCH_F512(0);
-#undef LAUNCH_F512
+    hipLaunchKernelGGL(fft512_kernel, dim3(b.tiles_f), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_f, t.hannz512,
+                       t.tw512, w.centroid, w.rolloff, w.flatness, w.flux, w.e256, w.zc256);
 }
 
 }  // namespace bg

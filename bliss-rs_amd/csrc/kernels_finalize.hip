@@ -18,36 +18,51 @@ namespace bg {
 
 __device__ __forceinline__ float normalize(float v, float mn, float mx) { return 2.0f * (v - mn) / (mx - mn) - 1.0f; }
 
-// The loops below are sequential by definition (they reproduce the reference's rounding order).  A wavefront
+// The chains below are sequential by definition (they reproduce the reference's rounding order).  A wavefront
 // executing ONE such chain still pays a full 4-cycle VALU issue per instruction, so the mapping is one LANE per
 // song: 64 songs advance their (independent) chains in lock step and a role costs 1/64 of the issue slots.
-// Loads are issued 16 elements at a time (16-byte loads once the lane's cursor is aligned) so the dependent
-// arithmetic chain never waits on memory.
-constexpr int SEQ_CHUNK = 16;
+//
+// Memory side: lane-per-song means 64 different streams, i.e. 64 different cache lines per load instruction if every
+// lane fetched its own stream.  Instead the wave stages the streams through LDS 64 elements at a time: for each of
+// its 64 songs it issues ONE coalesced 256-byte load (lane l fetches element base + l of song j; the song's base
+// pointer is a scalar read with v_readlane), the NEXT tile's 64 loads are in flight while the current tile is being
+// consumed, and every lane then walks its own row of the tile.  Rows are padded to 65 words, so both the row-wise
+// writes and the column-wise reads are bank-conflict free.
+constexpr int SEQ_TILE = 64;
 
-template <typename Step>
-__device__ __forceinline__ void seq_for_each(const float* __restrict__ x, uint32_t n, Step&& step) {
-    uint32_t i = 0;
-    while (i < n && ((reinterpret_cast<uintptr_t>(x + i) & 15) != 0)) { step(x[i], i); i++; }
-    for (; i + SEQ_CHUNK <= n; i += SEQ_CHUNK) {
-        float4 v[SEQ_CHUNK / 4];
+template <typename T, typename Step>
+__device__ __forceinline__ void staged_for_each(const T* __restrict__ x, uint32_t n, T (*tile)[SEQ_TILE + 1], Step&& step) {
+    const int lane = threadIdx.x;
+    uint32_t n_max = n;
 #pragma unroll
-        for (int u = 0; u < SEQ_CHUNK / 4; u++) v[u] = *reinterpret_cast<const float4*>(x + i + 4 * u);
+    for (int off = 32; off > 0; off >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, off, WAVE));
+    const uint64_t my_ptr = reinterpret_cast<uint64_t>(x);
+    T nxt[SEQ_TILE];
+    // one range-checked buffer load per song: lanes past the song's end read 0 (no exec masking, no clamping)
+    auto fetch = [&](uint32_t base) {
+        const uint32_t voff = (base + (uint32_t)lane) * 4u;
 #pragma unroll
-        for (int u = 0; u < SEQ_CHUNK / 4; u++) {
-            step(v[u].x, i + 4 * u);
-            step(v[u].y, i + 4 * u + 1);
-            step(v[u].z, i + 4 * u + 2);
-            step(v[u].w, i + 4 * u + 3);
+        for (int j = 0; j < SEQ_TILE; j++) {
+            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)my_ptr, j), hi = __builtin_amdgcn_readlane((uint32_t)(my_ptr >> 32), j);
+            const uint32_t nj = __builtin_amdgcn_readlane(n, j);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, nj * 4u, 0x00020000);
+            const uint32_t raw = __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
+            __builtin_memcpy(&nxt[j], &raw, 4);
         }
+    };
+    fetch(0);
+    for (uint32_t base = 0; base < n_max; base += SEQ_TILE) {
+#pragma unroll
+        for (int j = 0; j < SEQ_TILE; j++) tile[j][lane] = nxt[j];
+        __builtin_amdgcn_wave_barrier();
+        if (base + SEQ_TILE < n_max) fetch(base + SEQ_TILE);  // in flight while this tile is consumed
+        const uint32_t cnt = n > base ? (n - base < (uint32_t)SEQ_TILE ? n - base : (uint32_t)SEQ_TILE) : 0u;
+#pragma unroll 8
+        for (int e = 0; e < SEQ_TILE; e++)
+            if ((uint32_t)e < cnt) step(tile[lane][e], base + e);
+        __builtin_amdgcn_wave_barrier();
     }
-    for (; i < n; i++) step(x[i], i);
-}
-
-__device__ float seq_mean(const float* __restrict__ x, uint32_t n) {
-    float s = 0.0f;
-    seq_for_each(x, n, [&](float v, uint32_t) { s += v; });
-    return s / (float)n;
 }
 
 __device__ __forceinline__ void welford_step(float v, uint32_t i, float& mean, float& sum_sq) {
@@ -57,16 +72,11 @@ __device__ __forceinline__ void welford_step(float v, uint32_t i, float& mean, f
     sum_sq = __fmaf_rn(v - mean, delta, sum_sq);
 }
 
-__device__ float seq_std(const float* __restrict__ x, uint32_t n) {
-    float mean = 0.0f, sum_sq = 0.0f;
-    seq_for_each(x, n, [&](float v, uint32_t i) { welford_step(v, i, mean, sum_sq); });
-    return sqrtf(sum_sq / ((float)n - 0.0f));
-}
-
-enum Role { R_CENT_MEAN = 0, R_CENT_STD, R_ROLL_MEAN, R_ROLL_STD, R_FLAT_MEAN, R_FLAT_STD, R_LOUD, R_ZCR, R_COUNT };
+enum Role { R_CENT = 0, R_ROLL, R_FLAT, R_LOUD, R_ZCR, R_COUNT };
 
 // summary[s][0..15]: slots 1..9 = features 1..9 (zcr, centroid, rolloff, flatness, loudness)
-// grid = (ceil(n_songs / 64), R_COUNT): one wavefront = one role of 64 songs (lane = song)
+// grid = (ceil(n_songs / 64), R_COUNT): one wavefront = one role of 64 songs (lane = song).  A timbral role carries the
+// mean chain (one add per element) and the Welford chain of the same series: the series is staged once.
 __global__ __launch_bounds__(64) void summary_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                      const float* __restrict__ centroid,
                                                      const float* __restrict__ rolloff,
@@ -74,48 +84,64 @@ __global__ __launch_bounds__(64) void summary_kernel(const SongDesc* __restrict_
                                                      const float* __restrict__ e256,
                                                      const uint32_t* __restrict__ zc256,
                                                      float* __restrict__ summary) {
+    __shared__ float tile[SEQ_TILE][SEQ_TILE + 1];
     const uint32_t s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= n_songs) return;
-    const SongDesc sd = songs[s];
-    if (!sd.ok) return;
-    float* feat = summary + (size_t)s * 16;
+    // lanes past the batch (or too-short songs) take part in the staging with n = 0
+    SongDesc sd{};
+    if (s < n_songs) sd = songs[s];
+    const bool live = s < n_songs && sd.ok;
+    float* feat = summary + (size_t)(live ? s : 0) * 16;
     const float half_sr = (float)SAMPLE_RATE / 2.0f;
-    switch ((int)blockIdx.y) {  // wave-uniform
-        case R_CENT_MEAN: feat[2] = normalize(seq_mean(centroid + sd.t_off, sd.n_t), 0.0f, half_sr); break;
-        case R_CENT_STD: feat[3] = normalize(seq_std(centroid + sd.t_off, sd.n_t), 0.0f, half_sr); break;
-        case R_ROLL_MEAN: feat[4] = normalize(seq_mean(rolloff + sd.t_off, sd.n_t), 0.0f, half_sr); break;
-        case R_ROLL_STD: feat[5] = normalize(seq_std(rolloff + sd.t_off, sd.n_t), 0.0f, half_sr); break;
-        case R_FLAT_MEAN: feat[6] = 2.0f * (seq_mean(flatness + sd.t_off, sd.n_t) - 0.0f) / (1.0f - 0.0f) - 1.0f; break;
-        case R_FLAT_STD: feat[7] = 2.0f * (seq_std(flatness + sd.t_off, sd.n_t) - 0.0f) / (1.0f - 0.0f) - 1.0f; break;
-        case R_LOUD: {
-            // chunk level = sum of squares over <=1024 samples / len (src/misc.rs:12-18); the four
-            // 256-sample partial sums are added in order
-            const float* e = e256 + sd.e_off;
-            float msum = 0.0f, mean = 0.0f, sum_sq = 0.0f;
-            for (uint32_t c = 0; c < sd.n_l; c++) {
-                float en = 0.0f;
-                for (uint32_t q = 4 * c; q < 4 * c + 4 && q < sd.n_e; q++) en += e[q];
-                const uint64_t len = ((uint64_t)(c + 1) * LOUD_W <= sd.n) ? LOUD_W : sd.n - (uint64_t)c * LOUD_W;
-                const float v = en / (float)len;
-                msum += v;
-                welford_step(v, c, mean, sum_sq);
+    const int role = (int)blockIdx.y;  // wave-uniform
+    if (role <= R_FLAT) {
+        const float* series = role == R_CENT ? centroid : (role == R_ROLL ? rolloff : flatness);
+        const uint32_t n = live ? sd.n_t : 0u;
+        float sum = 0.0f, mean = 0.0f, sum_sq = 0.0f;
+        staged_for_each(series + (live ? sd.t_off : 0), n, tile, [&](float v, uint32_t i) {
+            sum += v;                            // utils::mean: sequential f32 sum
+            welford_step(v, i, mean, sum_sq);    // ndarray std_axis
+        });
+        if (live) {
+            const float mean_value = sum / (float)n;
+            const float std_value = sqrtf(sum_sq / ((float)n - 0.0f));
+            if (role == R_FLAT) {
+                feat[6] = 2.0f * (mean_value - 0.0f) / (1.0f - 0.0f) - 1.0f;
+                feat[7] = 2.0f * (std_value - 0.0f) / (1.0f - 0.0f) - 1.0f;
+            } else {
+                feat[role == R_CENT ? 2 : 4] = normalize(mean_value, 0.0f, half_sr);
+                feat[role == R_CENT ? 3 : 5] = normalize(std_value, 0.0f, half_sr);
             }
+        }
+    } else if (role == R_LOUD) {
+        // chunk level = sum of squares over <= 1024 samples / len (src/misc.rs:12-18); the four 256-sample partial
+        // sums of a chunk are added in order as they stream by
+        const uint32_t n = live ? sd.n_e : 0u;
+        float msum = 0.0f, mean = 0.0f, sum_sq = 0.0f, en = 0.0f;
+        staged_for_each(e256 + (live ? sd.e_off : 0), n, tile, [&](float v, uint32_t q) {
+            en += v;
+            if ((q & 3u) == 3u || q + 1 == n) {  // last block of chunk c = q / 4
+                const uint32_t c = q >> 2;
+                const uint64_t len = ((uint64_t)(c + 1) * LOUD_W <= sd.n) ? LOUD_W : sd.n - (uint64_t)c * LOUD_W;
+                const float lv = en / (float)len;
+                msum += lv;
+                welford_step(lv, c, mean, sum_sq);
+                en = 0.0f;
+            }
+        });
+        if (live) {
             float mean_value = msum / (float)sd.n_l;
             float std_value = sqrtf(sum_sq / ((float)sd.n_l - 0.0f));
             if (mean_value < 1e-9f) mean_value = 1e-9f;
             if (std_value < 1e-9f) std_value = 1e-9f;
             feat[8] = normalize(10.0f * log10f(mean_value), -90.0f, 0.0f);
             feat[9] = normalize(10.0f * log10f(std_value), -90.0f, 0.0f);
-            break;
         }
-        case R_ZCR: {
-            const uint32_t* z = zc256 + sd.e_off;
-            uint32_t c = 0;
-            for (uint32_t q = 0; q < sd.n_e; q++) c += z[q];
-            feat[1] = normalize((float)c / (float)sd.n, 0.0f, 1.0f);
-            break;
-        }
-        default: break;
+    } else {
+        const uint32_t n = live ? sd.n_e : 0u;
+        uint32_t c = 0;
+        staged_for_each(zc256 + (live ? sd.e_off : 0), n, reinterpret_cast<uint32_t(*)[SEQ_TILE + 1]>(tile),
+                        [&](uint32_t v, uint32_t) { c += v; });
+        if (live) feat[1] = normalize((float)c / (float)sd.n, 0.0f, 1.0f);
     }
 }
 

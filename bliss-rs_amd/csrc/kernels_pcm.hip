@@ -1,112 +1,12 @@
-// kernels_pcm.hip -- one coalesced pass over the batch PCM:
-//   * per 256-sample block: sum of squares (feeds LoudnessDesc, src/misc.rs:12-18,46-65, and the
-//     tempo silence test, src/aubio.rs:1258-1276) and zero-crossing count (number_crossings,
-//     src/utils.rs:81-95: a crossing is a change of `x > 0` between consecutive samples)
+// kernels_pcm.hip -- PCM in and out of the analysis format:
+//   * raw decoder output (s16 / f32, interleaved channels) -> the mono f32 PCM Song::analyze takes
 //   * Philox4x32-10 white-noise synthesis for the benchmark (no reference counterpart).
-// HBM-bound: 4 bytes read per sample, 8 bytes written per 256 samples.
+// (The per-block PCM statistics -- sums of squares, zero crossings -- are computed by the FFT-512 kernel, which
+// already holds every sample in registers: kernels_fft512.hip.)
 #include "device_utils.hpp"
 #include "internal.hpp"
 
 namespace bg {
-
-constexpr int PCM_TILE_BLOCKS = 16;  // 256-sample blocks per workgroup (4 per wave)
-
-__global__ __launch_bounds__(256) void pcm_stats_kernel(const float* __restrict__ pcm,
-                                                        const SongDesc* __restrict__ songs, uint32_t n_songs,
-                                                        const uint32_t* __restrict__ pfx_e, float* __restrict__ e256,
-                                                        uint32_t* __restrict__ zc256) {
-    const uint32_t s = find_segment(pfx_e, n_songs, blockIdx.x);
-    const SongDesc sd = songs[s];
-    const uint32_t tile = blockIdx.x - pfx_e[s];
-    const float* __restrict__ x = pcm + sd.pcm_off;
-    const int lane = lane_id(), wave = wave_id();
-    const bool aligned16 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-    {
-        // fast path: the wave's four blocks are complete and 16-byte aligned -> all four loads in flight at once
-        const uint32_t q0 = tile * PCM_TILE_BLOCKS + wave * (PCM_TILE_BLOCKS / 4);
-        if (aligned16 && (uint64_t)(q0 + PCM_TILE_BLOCKS / 4) * 256 <= sd.n) {  // wave-uniform
-            const uint64_t base0 = (uint64_t)q0 * 256;
-            float4 v[PCM_TILE_BLOCKS / 4];
-#pragma unroll
-            for (int i = 0; i < PCM_TILE_BLOCKS / 4; i++) {  // streamed once: non-temporal, the FFT kernels own the L2
-                typedef float f32x4_t __attribute__((ext_vector_type(4)));
-                const f32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(x + base0 + 256 * i + 4 * lane));
-                v[i] = make_float4(q.x, q.y, q.z, q.w);
-            }
-            uint32_t carry = (x[base0 > 0 ? base0 - 1 : 0] > 0.0f) ? 1u : 0u;  // positivity of the sample before the block
-            float ss[PCM_TILE_BLOCKS / 4];
-            uint32_t zc[PCM_TILE_BLOCKS / 4];
-#pragma unroll
-            for (int i = 0; i < PCM_TILE_BLOCKS / 4; i++) {
-                const float4 w = v[i];
-                ss[i] = (w.x * w.x + w.y * w.y) + (w.z * w.z + w.w * w.w);
-                const uint32_t p0 = w.x > 0.0f, p1 = w.y > 0.0f, p2 = w.z > 0.0f, p3 = w.w > 0.0f;
-                uint32_t before = __shfl_up(p3, 1, WAVE);
-                if (lane == 0) before = carry;
-                zc[i] = (p0 != before) + (p1 != p0) + (p2 != p1) + (p3 != p2);
-                carry = __shfl(p3, 63, WAVE);
-            }
-#pragma unroll
-            for (int i = 0; i < PCM_TILE_BLOCKS / 4; i++) {
-                const float s_tot = wave_sum(ss[i]);
-                const uint32_t z_tot = wave_sum(zc[i]);
-                if (lane == 0) {
-                    e256[sd.e_off + q0 + i] = s_tot;
-                    zc256[sd.e_off + q0 + i] = z_tot;
-                }
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < PCM_TILE_BLOCKS / 4; i++) {
-        const uint32_t q = tile * PCM_TILE_BLOCKS + wave * (PCM_TILE_BLOCKS / 4) + i;
-        if (q >= sd.n_e) break;  // wave-uniform
-        const uint64_t base = (uint64_t)q * 256;
-        // positivity of the sample before the block (the first sample of the song compares with itself)
-        uint32_t prev_pos = (x[base > 0 ? base - 1 : 0] > 0.0f) ? 1u : 0u;
-        float ss = 0.0f;
-        uint32_t zc = 0;
-        if (aligned16 && base + 256 <= sd.n) {  // wave-uniform: one 16-byte load per lane covers the block
-            const float4 v = *reinterpret_cast<const float4*>(x + base + 4 * lane);
-            ss = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-            const uint32_t p0 = v.x > 0.0f, p1 = v.y > 0.0f, p2 = v.z > 0.0f, p3 = v.w > 0.0f;
-            uint32_t before = __shfl_up(p3, 1, WAVE);
-            if (lane == 0) before = prev_pos;
-            zc = (p0 != before) + (p1 != p0) + (p2 != p1) + (p3 != p2);
-            ss = wave_sum(ss);
-            zc = wave_sum(zc);
-            if (lane == 0) {
-                e256[sd.e_off + q] = ss;
-                zc256[sd.e_off + q] = zc;
-            }
-            continue;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint64_t idx = base + j * 64 + lane;
-            const bool valid = idx < sd.n;
-            const float v = valid ? x[idx] : 0.0f;
-            ss += v * v;
-            const uint64_t pos = __ballot(valid && v > 0.0f);
-            const uint64_t vmask = __ballot(valid);
-            const uint64_t shifted = (pos << 1) | (uint64_t)prev_pos;
-            zc += (uint32_t)__popcll((pos ^ shifted) & vmask);
-            prev_pos = (uint32_t)(pos >> 63);
-        }
-        ss = wave_sum(ss);
-        if (lane == 0) {
-            e256[sd.e_off + q] = ss;
-            zc256[sd.e_off + q] = zc;
-        }
-    }
-}
-
-void launch_pcm_stats(const Batch& b, const Workspace& w, hipStream_t st) {
-    if (b.tiles_e == 0) return;
-    hipLaunchKernelGGL(pcm_stats_kernel, dim3(b.tiles_e), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_e,
-                       w.e256, w.zc256);
-}
 
 // ---- raw decoder output -> the mono f32 PCM Song::analyze takes (the PCM feed) ----
 //   s16 -> f32   : sample / 32768 (exact in f32), FFmpeg's AV_SAMPLE_FMT_S16 -> FLT conversion as used by the reference's

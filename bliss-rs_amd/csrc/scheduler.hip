@@ -3,11 +3,11 @@
 // analysis (src/song/mod.rs:432-491).
 //
 //   plan      songs are ordered by length (longest first: "length bucketing") and cut into chunks whose scratch
-//             workspace fits one of the context's TWO chunk slots;
-//   schedule  chunk k runs its FFT / chroma chain on the context's main stream and its per-song tails (PCM statistics,
-//             sequential summaries, beat tracker, row assembly) on the aux stream.  Nothing on the main stream ever
-//             waits for a tail, so chunk k + 1's FFT kernels start right behind chunk k's chroma contraction while
-//             chunk k's tails are still running; a slot is reused two chunks later, after its own assembly;
+//             workspace fits one of the context's TWO chunk slots (big batches into at least four chunks);
+//   schedule  a chunk is enqueued in two halves -- front: the FFT kernels on the main stream, its per-song tails and its
+//             tuning estimate on two high-priority side streams; back: the chroma contraction and the row assembly -- and
+//             the back half of chunk k follows the front half of chunk k + 1, so the latency-bound kernels of one chunk
+//             hide beside the FFT kernels of the next; a slot is reused two chunks later, after its own assembly;
 //   feed      host PCM (f32 or s16, mono or interleaved multi-channel) is shipped group by group into two device
 //             buffers, the copy of group g + 1 overlapping the analysis of group g;
 //   front     concurrent single-song calls (N worker threads each calling Song::analyze, src/song/decoder.rs:299-329)
@@ -95,21 +95,25 @@ Workspace carve(uint8_t* base, uint32_t ns, const ChunkTotals& t, size_t* bytes)
 
 int ensure_slot_events(ChunkSlot& s) {
     if (s.ev_free) return BLISSGPU_OK;
-    hipEvent_t* evs[] = {&s.ev_start, &s.ev_fork, &s.ev_stft, &s.ev_chroma, &s.ev_desc, &s.ev_free};
+    hipEvent_t* evs[] = {&s.ev_start, &s.ev_fork, &s.ev_stft, &s.ev_tune, &s.ev_sum, &s.ev_chroma, &s.ev_desc, &s.ev_free};
     for (hipEvent_t* e : evs) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     return BLISSGPU_OK;
 }
 
-// One chunk = the songs [songs, songs + ns) (already ordered).  Everything is enqueued; nothing here waits for the
-// device except the reuse of a slot's pinned descriptor staging (two chunks back) and buffer growth.
-int run_chunk(blissgpu_ctx* c, const float* d_pcm, SongDesc* songs, uint32_t ns, uint32_t features_version, float* d_out,
-              int32_t* d_status) {
-    if (ns == 0) return BLISSGPU_OK;
-    ChunkSlot& slot = c->slot[c->chunk_seq & 1];
+// One chunk = the songs [songs, songs + ns) (already ordered), enqueued in two halves so that a batch is software-pipelined
+// at enqueue time (see blissgpu_analyze_batch_device):
+//   front  descriptors, FFT-512 + onset, FFT-8192 on the main stream; behind them, on the two high-priority side streams,
+//          the per-song tails (sequential summaries, beat tracker: they need only the FFT-512 series) beside the FFT-8192
+//          kernel, and the tuning estimate (histogram walk, radix select) beside whatever the main stream runs next;
+//   back   the chroma contraction (needs the tuning) on the main stream and the row assembly on the aux stream.
+// The back half of chunk k is enqueued AFTER the front half of chunk k + 1: the latency-bound tuning kernels of chunk k
+// then hide beside chunk k + 1's FFT kernels instead of sitting between the FFT-8192 kernel and the contraction.
+// Nothing here waits for the device except the reuse of a slot's pinned descriptor staging and buffer growth.
+int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* songs, uint32_t ns) {
     int rc = ensure_slot_events(slot);
     if (rc) return rc;
     // ---- offsets into the batch-wide series + tile prefixes ----
-    std::vector<uint32_t> pfx_e(ns + 1, 0), pfx_f(ns + 1, 0), pfx_c(ns + 1, 0), pfx_ct(ns + 1, 0), pfx_cw(ns + 1, 0);
+    std::vector<uint32_t> pfx_f(ns + 1, 0), pfx_c(ns + 1, 0), pfx_ct(ns + 1, 0), pfx_cw(ns + 1, 0);
     ChunkTotals t;
     for (uint32_t i = 0; i < ns; i++) {
         SongDesc& d = songs[i];
@@ -120,7 +124,6 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, SongDesc* songs, uint32_t ns,
             t.max_nt = std::max(t.max_nt, d.n_t);
             t.max_runs = std::max(t.max_runs, d.n_b / BT_STEP + 1);
         }
-        pfx_e[i + 1] = pfx_e[i] + (d.ok ? (d.n_e + 15) / 16 : 0);
         pfx_f[i + 1] = pfx_f[i] + (d.ok ? (d.n_f + F512_TILE - 1) / F512_TILE : 0);
         pfx_c[i + 1] = pfx_c[i] + (d.ok ? (d.n_c + STFT_TILE - 1) / STFT_TILE : 0);
         pfx_ct[i + 1] = pfx_ct[i] + (d.ok ? (d.n_c + CH_TILE - 1) / CH_TILE : 0);
@@ -133,7 +136,7 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, SongDesc* songs, uint32_t ns,
     t.cand_cap = std::min<uint64_t>(t.tot_c * (uint64_t)c->cand_budget, 0xFFFFFF00ull) + 64;
 
     // ---- buffers of the slot (growth frees the old block, which waits for the device) ----
-    const size_t desc_bytes = align_up(ns * sizeof(SongDesc), 256) + 5 * align_up((ns + 1) * 4, 256);
+    const size_t desc_bytes = align_up(ns * sizeof(SongDesc), 256) + 4 * align_up((ns + 1) * 4, 256);
     size_t need = 0;
     (void)carve(nullptr, ns, t, &need);
     if ((rc = slot.desc.ensure(desc_bytes))) return rc;
@@ -141,15 +144,14 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, SongDesc* songs, uint32_t ns,
     if (slot.used) HIP_TRY(hipEventSynchronize(slot.ev_desc));  // the slot's previous descriptor copy has left the staging area
     if ((rc = slot.h_desc.ensure(desc_bytes))) return rc;
 
-    hipStream_t st = c->stream, sb = c->serial ? c->stream : c->aux_stream;
-    const bool two = !c->serial;
+    hipStream_t st = c->stream, sb = c->serial ? c->stream : c->aux_stream, sc = c->serial ? c->stream : c->chr_stream;
+    const bool multi = !c->serial;
     // the slot's previous chunk (two chunks back) must have assembled its rows before its workspace is overwritten
-    if (slot.used && two) HIP_TRY(hipStreamWaitEvent(st, slot.ev_free, 0));
+    if (slot.used && multi) HIP_TRY(hipStreamWaitEvent(st, slot.ev_free, 0));
 
     uint8_t* h = slot.h_desc.p;
     size_t o = 0;
     const size_t o_songs = o; memcpy(h + o, songs, ns * sizeof(SongDesc)); o = align_up(o + ns * sizeof(SongDesc), 256);
-    const size_t o_e = o; memcpy(h + o, pfx_e.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
     const size_t o_f = o; memcpy(h + o, pfx_f.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
     const size_t o_c = o; memcpy(h + o, pfx_c.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
     const size_t o_ct = o; memcpy(h + o, pfx_ct.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
@@ -158,65 +160,64 @@ int run_chunk(blissgpu_ctx* c, const float* d_pcm, SongDesc* songs, uint32_t ns,
     HIP_TRY(hipEventRecord(slot.ev_desc, st));
     slot.used = true;
 
-    Batch b{};
+    Batch& b = slot.batch;
+    b = Batch{};
     b.pcm = d_pcm;
     b.songs = reinterpret_cast<const SongDesc*>(slot.desc.p + o_songs);
     b.n_songs = ns;
-    b.pfx_e = reinterpret_cast<const uint32_t*>(slot.desc.p + o_e);
     b.pfx_f = reinterpret_cast<const uint32_t*>(slot.desc.p + o_f);
     b.pfx_c = reinterpret_cast<const uint32_t*>(slot.desc.p + o_c);
     b.pfx_ct = reinterpret_cast<const uint32_t*>(slot.desc.p + o_ct);
     b.pfx_cw = reinterpret_cast<const uint32_t*>(slot.desc.p + o_cw);
-    b.tiles_e = pfx_e[ns]; b.tiles_f = pfx_f[ns]; b.tiles_c = pfx_c[ns]; b.tiles_ct = pfx_ct[ns]; b.tiles_cw = pfx_cw[ns];
+    b.tiles_f = pfx_f[ns]; b.tiles_c = pfx_c[ns]; b.tiles_ct = pfx_ct[ns]; b.tiles_cw = pfx_cw[ns];
     b.total_b = t.tot_b; b.max_nb = t.max_nb; b.max_nt = t.max_nt;
 
     size_t used_bytes = 0;
-    const Workspace w = carve(slot.slab.p, ns, t, &used_bytes);
+    slot.ws = carve(slot.slab.p, ns, t, &used_bytes);
+    const Workspace& w = slot.ws;
     c->last_ws = w;
     c->last_songs.assign(songs, songs + ns);
 
-    // The reference runs the five descriptors as scoped threads (src/song/mod.rs:432-491).  Here the two FFT-heavy
-    // kernels and the chroma chain run back to back on the main stream; the latency-bound tails of the tempo / timbral /
-    // loudness chains (one workgroup or one lane per song) and the row assembly run on the aux stream.
     HIP_TRY(hipMemsetAsync(w.h1, 0, (size_t)ns * H1_BINS * 4, st));
     HIP_TRY(hipMemsetAsync(w.hist100, 0, (size_t)ns * N_TUNING * 4, st));
     HIP_TRY(hipMemsetAsync(w.cand_cursor, 0, 16, st));
-    if (two) {
-        HIP_TRY(hipEventRecord(slot.ev_start, st));
-        HIP_TRY(hipStreamWaitEvent(sb, slot.ev_start, 0));
-    }
-    // aux: the HBM-bound PCM statistics pass (only the tails consume it) runs beside the VALU-bound FFT-512
-    { Prof p(c, K_PCM_STATS, sb); launch_pcm_stats(b, w, sb); }
     { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st); }
     { Prof p(c, K_ONSET); launch_onset(b, w, st); }
-    // aux: the sequential summaries (one lane per song, memory-latency bound) start as soon as the FFT-512 series
-    // exist and run beside the FFT-8192 kernel
-    if (two) {
+    // tails: the reference runs them as the tempo / timbral / loudness threads of src/song/mod.rs:432-491
+    if (multi) {
         HIP_TRY(hipEventRecord(slot.ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(sb, slot.ev_fork, 0));
     }
     { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
-    { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st); }
-    // The beat tracker (one 256-thread workgroup per song) would displace FFT-8192 workgroups, so it starts only after
-    // that kernel and runs beside the HBM-bound tuning / chroma kernels -- and, in a multi-chunk batch, beside the next
-    // chunk's FFT-512.
-    if (two) {
-        HIP_TRY(hipEventRecord(slot.ev_stft, st));
-        HIP_TRY(hipStreamWaitEvent(sb, slot.ev_stft, 0));
-    }
     { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
-    { Prof p(c, K_TUNE_SELECT); launch_tune_select(b, w, st); }
-    { Prof p(c, K_TUNE_PASS2); launch_tune_pass2(b, w, st); }
-    { Prof p(c, K_TUNE_FINAL); launch_tune_final(b, w, st); }
-    { Prof p(c, K_CHROMA); launch_chroma(b, w, c->tables, st); }
-    if (two) {
-        HIP_TRY(hipEventRecord(slot.ev_chroma, st));
-        HIP_TRY(hipStreamWaitEvent(sb, slot.ev_chroma, 0));
+    { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st); }
+    if (multi) {
+        HIP_TRY(hipEventRecord(slot.ev_stft, st));
+        HIP_TRY(hipStreamWaitEvent(sc, slot.ev_stft, 0));
     }
-    { Prof p(c, K_FINALIZE, sb); launch_finalize(b, w, features_version, d_out, d_status, c->dbg_tuning.p, c->dbg_nbpms.p, sb); }
-    if (two) HIP_TRY(hipEventRecord(slot.ev_free, sb));
+    { Prof p(c, K_TUNE_SELECT, sc); launch_tune_select(b, w, sc); }
+    { Prof p(c, K_TUNE_PASS2, sc); launch_tune_pass2(b, w, sc); }
+    { Prof p(c, K_TUNE_FINAL, sc); launch_tune_final(b, w, sc); }
+    if (multi) HIP_TRY(hipEventRecord(slot.ev_tune, sc));
     HIP_TRY(hipGetLastError());
-    c->chunk_seq++;
+    slot.back_pending = true;
+    return BLISSGPU_OK;
+}
+
+int chunk_back(blissgpu_ctx* c, ChunkSlot& slot, uint32_t features_version, float* d_out, int32_t* d_status) {
+    if (!slot.back_pending) return BLISSGPU_OK;
+    slot.back_pending = false;
+    hipStream_t st = c->stream, sb = c->serial ? c->stream : c->aux_stream;
+    const bool multi = !c->serial;
+    if (multi) HIP_TRY(hipStreamWaitEvent(st, slot.ev_tune, 0));
+    { Prof p(c, K_CHROMA); launch_chroma(slot.batch, slot.ws, c->tables, st); }
+    if (multi) {
+        HIP_TRY(hipEventRecord(slot.ev_chroma, st));
+        HIP_TRY(hipStreamWaitEvent(sb, slot.ev_chroma, 0));  // aux already holds the chunk's summaries and beat tracker
+    }
+    { Prof p(c, K_FINALIZE, sb); launch_finalize(slot.batch, slot.ws, features_version, d_out, d_status, c->dbg_tuning.p, c->dbg_nbpms.p, sb); }
+    if (multi) HIP_TRY(hipEventRecord(slot.ev_free, sb));
+    HIP_TRY(hipGetLastError());
     return BLISSGPU_OK;
 }
 
@@ -227,7 +228,7 @@ namespace bg {
 void scheduler_release(blissgpu_ctx* c) {
     for (ChunkSlot& s : c->slot) {
         s.slab.release(); s.desc.release(); s.h_desc.release();
-        hipEvent_t evs[] = {s.ev_start, s.ev_fork, s.ev_stft, s.ev_chroma, s.ev_desc, s.ev_free};
+        hipEvent_t evs[] = {s.ev_start, s.ev_fork, s.ev_stft, s.ev_tune, s.ev_sum, s.ev_chroma, s.ev_desc, s.ev_free};
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
         s = ChunkSlot{};
@@ -472,25 +473,34 @@ int blissgpu_analyze_batch_device(blissgpu_ctx* c, const float* d_pcm, const uin
         if (d.ok) fill_counts(d);
     }
     std::stable_sort(songs.begin(), songs.end(), [](const SongDesc& a, const SongDesc& b) { return a.n > b.n; });
-    // ---- chunks: as many songs as fit one slot's workspace ----
+    // ---- chunks: as many songs as fit one slot's workspace -- and at least PIPELINE_CHUNKS of them when the batch is big
+    // enough to fill the GPU several times over, so that the software pipeline below has something to overlap ----
     struct Range { uint32_t b, e; };
     std::vector<Range> todo;
     {
+        size_t total_bytes = 0;
+        for (uint32_t i = 0; i < n_songs; i++) total_bytes += song_ws_bytes(songs[i]);
+        size_t limit = c->ws_limit;
+        if (!c->serial && c->pipeline_chunks > 1 && total_bytes / c->pipeline_chunks >= (size_t)PIPELINE_MIN_CHUNK_BYTES)
+            limit = std::min<size_t>(limit, total_bytes / c->pipeline_chunks + 1);
         size_t bytes = 0;
         uint32_t b0 = 0;
         for (uint32_t i = 0; i < n_songs; i++) {
             const size_t sb = song_ws_bytes(songs[i]);
-            if (i > b0 && bytes + sb > c->ws_limit) { todo.push_back({b0, i}); b0 = i; bytes = 0; }
+            if (i > b0 && bytes + sb > limit) { todo.push_back({b0, i}); b0 = i; bytes = 0; }
             bytes += sb;
         }
         todo.push_back({b0, n_songs});
     }
     std::reverse(todo.begin(), todo.end());  // used as a stack
     uint64_t chunks = 0;
+    ChunkSlot* prev = nullptr;  // the chunk whose back half is still to be enqueued
     while (!todo.empty()) {
         const Range r = todo.back();
         todo.pop_back();
-        rc = run_chunk(c, d_pcm, songs.data() + r.b, r.e - r.b, features_version, d_out, d_status);
+        ChunkSlot& slot = c->slot[c->chunk_seq & 1];
+        // the slot's own back half (chunk k - 2) is always enqueued by now; its front may only follow it
+        rc = chunk_front(c, slot, d_pcm, songs.data() + r.b, r.e - r.b);
         if (rc == BLISSGPU_ERR_OOM && r.e - r.b > 1) {
             // the device has less free memory than the limit assumed (another process, the caller's own tensors):
             // halve the chunk and go on
@@ -501,8 +511,13 @@ int blissgpu_analyze_batch_device(blissgpu_ctx* c, const float* d_pcm, const uin
             continue;
         }
         if (rc) return rc;
+        c->chunk_seq++;
         chunks++;
+        if (prev && (rc = chunk_back(c, *prev, features_version, d_out, d_status))) return rc;
+        prev = &slot;
+        if (c->serial) { if ((rc = chunk_back(c, slot, features_version, d_out, d_status))) return rc; prev = nullptr; }
     }
+    if (prev && (rc = chunk_back(c, *prev, features_version, d_out, d_status))) return rc;
     c->last_chunks = chunks;
     // the caller-visible stream has "done" everything once the tails of the (at most two) chunks in flight are in
     if (!c->serial)
