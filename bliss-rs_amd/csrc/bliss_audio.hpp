@@ -180,10 +180,33 @@ struct Song {
     FeaturesVersion features_version = LATEST;
 
     static Analysis analyze(const std::vector<float>& sample_array) { return analyze_with_options(sample_array, AnalysisOptions{}); }
+    // One song through blissgpu_analyze: safe from any number of threads (the reference's worker pool,
+    // src/song/decoder.rs:299-329); concurrent calls are coalesced into one device batch inside the library.
     static Analysis analyze_with_options(const std::vector<float>& sample_array, const AnalysisOptions& opt) {
-        auto r = analyze_batch({sample_array}, opt);
-        if (auto* e = std::get_if<BlissError>(&r[0])) throw *e;  // Err(AnalysisError("empty or too short song."))
-        return std::get<Analysis>(std::move(r[0]));
+        std::vector<float> out(feature_count(opt.features_version));
+        int32_t status = 0;
+        const float dummy = 0.0f;
+        check(blissgpu_analyze(sample_array.empty() ? &dummy : sample_array.data(), sample_array.size(),
+                               static_cast<uint32_t>(opt.features_version), out.data(), &status));
+        if (status != BLISSGPU_SONG_OK) throw AnalysisError("empty or too short song.");  // Err(...), src/song/mod.rs:426-430
+        return Analysis(std::move(out), opt.features_version);
+    }
+    // Raw decoder output: `channels` interleaved channels of f32 (or s16, overload below) at 22 050 Hz; the mono downmix
+    // ((L + R) * SQRT_2 / 2 for stereo, src/song/decoder/symphonia.rs:266-300) runs on the device.
+    static Analysis analyze_interleaved(const std::vector<float>& samples, uint32_t channels, const AnalysisOptions& opt = {}) {
+        return analyze_raw(samples.data(), BLISSGPU_SAMPLE_F32, channels, samples.size() / (channels ? channels : 1), opt);
+    }
+    static Analysis analyze_interleaved(const std::vector<int16_t>& samples, uint32_t channels, const AnalysisOptions& opt = {}) {
+        return analyze_raw(samples.data(), BLISSGPU_SAMPLE_S16, channels, samples.size() / (channels ? channels : 1), opt);
+    }
+    static Analysis analyze_raw(const void* pcm, int sample_format, uint32_t channels, uint64_t frames, const AnalysisOptions& opt) {
+        std::vector<float> out(feature_count(opt.features_version));
+        int32_t status = 0;
+        const float dummy = 0.0f;
+        check(blissgpu_analyze_interleaved(frames ? pcm : &dummy, sample_format, channels, frames,
+                                           static_cast<uint32_t>(opt.features_version), out.data(), &status));
+        if (status != BLISSGPU_SONG_OK) throw AnalysisError("empty or too short song.");
+        return Analysis(std::move(out), opt.features_version);
     }
     float distance(const Song& other) const { return analysis.distance(other.analysis); }
 };

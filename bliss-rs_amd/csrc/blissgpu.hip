@@ -153,6 +153,7 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
     // instead of queueing behind the thousands of workgroups of an FFT kernel
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (const char* e = getenv("BLISSGPU_SIDE_PRIORITY")) { if (atoi(e) == 0) prio_greatest = prio_least; }  // developer aid
     se = hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio_greatest);
     if (se == hipSuccess) se = hipStreamCreateWithPriority(&c->chr_stream, hipStreamNonBlocking, prio_greatest);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_interop, hipEventDisableTiming);

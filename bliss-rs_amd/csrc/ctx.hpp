@@ -107,7 +107,8 @@ struct blissgpu_ctx {
     hipStream_t stream = nullptr;      // FFT + chroma chain (the caller-visible stream)
     hipStream_t aux_stream = nullptr;  // per-song tails: PCM statistics, summaries, beat tracker, row assembly
     hipStream_t chr_stream = nullptr;  // tuning estimate of a chunk, beside the next chunk's FFT kernels
-    uint32_t pipeline_chunks = 4;      // big batches are cut into at least this many chunks (BLISSGPU_PIPELINE_CHUNKS)
+    uint32_t pipeline_chunks = 1;      // cut big batches into at least this many chunks (BLISSGPU_PIPELINE_CHUNKS; measured: the
+                                       // per-song tails have a fixed latency per launch, so more chunks than memory needs lose)
     hipEvent_t ev_interop = nullptr;
     bool serial = false;               // BLISSGPU_SERIAL=1: single stream (clean per-kernel timings)
     uint64_t ws_limit = 0;             // bytes per chunk slot (set from the free device memory at creation)

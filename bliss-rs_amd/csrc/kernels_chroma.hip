@@ -245,6 +245,7 @@ constexpr int LHIST_BINS = 512;  // 16 octaves of 32 coarse bins
 constexpr int EX1_PITCH = 257;   // k1-major rows of 256 (+1): the 16 lanes of a ds_read2_b64 group tile all 32 banks
 constexpr int EX2_PITCH = 272;   // j1-major rows of 256 (+16): shifts odd rows by 32 banks
 constexpr int STFT_LDS = 16 * EX2_PITCH;  // float2 elements (34 816 B)
+constexpr int MAGS_TOP = 2 * 4096;        // word index (of the exchange buffer) where magnitude words 4096..4111 live
 
 // W_32^j = (cos, -sin)(2 pi j / 32), j < 8
 __device__ constexpr float CONST_COS32[8] = {1.0f, 0.98078528040323044f, 0.92387953251128674f, 0.83146961230254524f,
@@ -268,8 +269,8 @@ __device__ __forceinline__ long reflect_index(long p, long n) {
     return p;
 }
 
-template <int ABL, int OCC>  // ABL != 0: timing ablations (developer aid, BLISSGPU_ABL), results are wrong
-__global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restrict__ pcm,
+// 4 workgroups per CU: 128 VGPRs, spill-free
+__global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restrict__ pcm,
                                                        const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                        const uint32_t* __restrict__ pfx_c,
                                                        const float* __restrict__ hann,
@@ -327,12 +328,8 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
     // raw samples of one frame: z[256*n1 + t] = (x[w0 + 2n], x[w0 + 2n + 1]), reflect only at the song edges
     auto load_frame = [&](uint32_t f, f2 (&xr)[16]) {
         const long w0 = (long)f * HOP_C - W8192 / 2;
-        if (ABL == 3) {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) xr[n1] = mk((float)(t + n1 + (int)f), 1.0f);
-        } else if (w0 >= 0 && w0 + W8192 <= n) {
-            const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(ABL == 4 ? pcm + 4096 : (ABL == 9 ? x + (w0 & ~3L) : x + w0)), 0, W8192 * 4, 0x00020000);
+        if (w0 >= 0 && w0 + W8192 <= n) {
+            const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + w0), 0, W8192 * 4, 0x00020000);
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) xr[n1] = buf_load_f2(r_x, t8, 2048u * n1);
         } else {
@@ -371,35 +368,29 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
         radix16(v);
 #pragma unroll
         for (int k1 = 1; k1 < 16; k1++)
-            v[R16(k1)] = cmul_pk(v[R16(k1)], (ABL == 5 || ABL == 14) ? mk(0.6f, 0.8f) : tw256[16 * k1 + hi4]);
+            v[R16(k1)] = cmul_pk(v[R16(k1)], tw256[16 * k1 + hi4]);
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) lds[k1 * EX1_PITCH + t] = v[R16(k1)];
         __syncthreads();
         // ---- pass 2: thread (k1 = lo4, m2 = hi4): DFT over m1; twiddle W_4096^(m2 k1) * W_256^(m2 j1) ----
 #pragma unroll
-        for (int m1 = 0; m1 < 16; m1++) v[m1] = ABL == 8 ? lds[t + 256 * m1] : lds[lo4 * EX1_PITCH + 16 * m1 + hi4];
+        for (int m1 = 0; m1 < 16; m1++) v[m1] = lds[lo4 * EX1_PITCH + 16 * m1 + hi4];
         radix16(v);
         v[R16(0)] = cmul_pk(v[R16(0)], c_p2);
 #pragma unroll
-        for (int j1 = 1; j1 < 16; j1++) v[R16(j1)] = cmul_pk(v[R16(j1)], cmul_pk(ABL == 14 ? mk(0.6f, 0.8f + j1) : tw256[16 * j1 + hi4], c_p2));
+        for (int j1 = 1; j1 < 16; j1++) v[R16(j1)] = cmul_pk(v[R16(j1)], cmul_pk(tw256[16 * j1 + hi4], c_p2));
         __syncthreads();
-        if (ABL != 11 && ABL != 12) {
 #pragma unroll
-            for (int j1 = 0; j1 < 16; j1++) lds[j1 * EX2_PITCH + t] = v[R16(j1)];  // = j1*272 + m2*16 + k1
-            __syncthreads();
-            // ---- pass 3: thread (k1 = lo4, j1 = hi4): DFT over m2 -> Z[t + 256*j2] ----
+        for (int j1 = 0; j1 < 16; j1++) lds[j1 * EX2_PITCH + t] = v[R16(j1)];  // = j1*272 + m2*16 + k1
+        __syncthreads();
+        // ---- pass 3: thread (k1 = lo4, j1 = hi4): DFT over m2 -> Z[t + 256*j2] ----
 #pragma unroll
-            for (int m2 = 0; m2 < 16; m2++) v[m2] = lds[hi4 * EX2_PITCH + 16 * m2 + lo4];
-        }
-        if (ABL != 11) radix16(v);
+        for (int m2 = 0; m2 < 16; m2++) v[m2] = lds[hi4 * EX2_PITCH + 16 * m2 + lo4];
+        radix16(v);
         __syncthreads();
         // only the upper half (bins 2049..4095, the mirrors of this workgroup's bins 1..2047) is ever read back
 #pragma unroll
         for (int j2 = 8; j2 < 16; j2++) lds[t + 256 * j2] = v[R16(j2)];
-        if (ABL == 15) {
-#pragma unroll
-            for (int j2 = 0; j2 < 8; j2++) lds[t + 256 * j2] = v[R16(j2)];
-        }
         __syncthreads();
         // ---- real-input split + magnitude (src/utils.rs:60).  Z[k] and Z[4096-k] yield X[k] AND X[4096-k]:
         // thread t pairs its bins k = t + 256 j, j < 8, with their mirrors (k = 0 pairs DC with Nyquist);
@@ -411,13 +402,10 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
             const float CJ = CONST_COS32[j], SJ = CONST_SIN32[j];
             const int k = t + 256 * j;
             float sq_k, sq_m;
-            if (ABL == 2) { sq_k = v[R16(j)].x; sq_m = v[R16(j)].y; }
-            else {
-                const f2 w = ABL == 6 ? mk(0.6f, 0.8f) : (j == 0 ? c_sp : cmul_pk_s(c_sp, mk(CJ, -SJ)));
-                // k = 0 pairs DC with itself (thread 0's own register); every other mirror is in the upper half
-                const f2 zm = lds[k == 0 ? 2048 : 4096 - k];
-                split_pair_sq(v[R16(j)], (j == 0 && t == 0) ? v[R16(0)] : zm, w, sq_k, sq_m);
-            }
+            const f2 w = j == 0 ? c_sp : cmul_pk_s(c_sp, mk(CJ, -SJ));
+            // k = 0 pairs DC with itself (thread 0's own register); every other mirror is in the upper half
+            const f2 zm = lds[k == 0 ? 2048 : 4096 - k];
+            split_pair_sq(v[R16(j)], (j == 0 && t == 0) ? v[R16(0)] : zm, w, sq_k, sq_m);
             m_lo[j] = mag_from_sq(sq_k);
             m_hi[j] = mag_from_sq(sq_m);
             mx = fmaxf(mx, fmaxf(m_lo[j], m_hi[j]));
@@ -429,15 +417,19 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
         const bool has_next = fi + 1 < STFT_FRAMES_PER_WG && f + 1 < sd.n_c;  // uniform
         if (has_next) load_frame(f + 1, v);
         mx = wave_max(mx);
-        __syncthreads();  // all split reads of lds are done
+        // The split only reads the UPPER half of the exchange buffer (complex slots 2049..4095 = bytes 16 392..32 767);
+        // the row of 4112 magnitudes goes into the dead lower half (words 0..4095) and, for bin 4096 and the zero padding,
+        // into the 2 KB behind the upper half -- no barrier between the split reads and these writes.
         float* mags = reinterpret_cast<float*>(lds);
+        float* mags_top = mags + MAGS_TOP - 4096;  // mags_top[4096 + i] = word MAGS_TOP + i
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             mags[t + 256 * j] = m_lo[j];
-            mags[4096 - (t + 256 * j)] = m_hi[j];
+            if (j == 0 && t == 0) mags_top[4096] = m_hi[0];  // bin 4096 (Nyquist)
+            else mags[4096 - (t + 256 * j)] = m_hi[j];
         }
         if (t == 0) mags[2048] = m_mid;
-        if (t >= 1 && t < CBINS_PAD - 4096) mags[4096 + t] = 0.0f;  // zero padding after bin 4096
+        if (t >= 1 && t < CBINS_PAD - 4096) mags_top[4096 + t] = 0.0f;  // zero padding after bin 4096
         {
             // the slot index is re-derived from the thread id inside the loop: kept live across the whole frame loop
             // it was the first register to be spilled, and its reload forced a vmcnt(0) drain per frame
@@ -450,16 +442,16 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
         // The spectrogram row goes to HBM from the LDS copy as 16-byte stores (5 per thread instead of 18 scalar
         // ones).  They are issued BEHIND the next frame's loads: vmcnt retires in order, so the wait for those
         // loads at the end of the iteration is "all but the stores" and never waits for an HBM write acknowledge.
-        if (ABL != 7) {
+        {
             const __amdgpu_buffer_rsrc_t r_row = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(spec + (sd.c_off + (ABL == 16 ? (f & 15) : f)) * (size_t)CBINS_PAD), 0, CBINS_PAD * 4, 0x00020000);
+                (void*)(spec + (sd.c_off + f) * (size_t)CBINS_PAD), 0, CBINS_PAD * 4, 0x00020000);
             const u32x4_t* mags4 = reinterpret_cast<const u32x4_t*>(lds);
 #pragma unroll
             for (int i = 0; i < 5; i++) {
                 const int q = t + 256 * i;
                 if (i < 4 || q < CBINS_PAD / 4) {
-                    if (ABL == 17) __builtin_amdgcn_raw_buffer_store_b128(mags4[q], r_row, 16u * (uint32_t)q, 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b128(mags4[q], r_row, 16u * (uint32_t)q, 0, 2);  // nt: streamed once
+                    const u32x4_t val = i < 4 ? mags4[q] : mags4[q - 1024 + MAGS_TOP / 4];
+                    __builtin_amdgcn_raw_buffer_store_b128(val, r_row, 16u * (uint32_t)q, 0, 2);  // nt: streamed once
                 }
             }
         }
@@ -479,7 +471,7 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
         // wavefronts instead of six times under a one-third-full exec mask ----
         const double ref = 0.1 * (double)mx;
         const float thr = ref_floor_f32(ref);
-        if (ABL != 1) {
+        {
             uint32_t hits = 0;  // bit j: bin t + 256 j is a peak
 #pragma unroll
             for (int j = 0; j < 6; j++) {
@@ -506,8 +498,7 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
                 int pb;
                 const uint32_t b = peak_classify(sb, se, sa, ref, c, &pb), rel = b - lbase;
                 recs[i] = peak_record(b, pb, c);
-                if (ABL == 13) { if (rel == 0x7fffffffu) lhist[0] = 1; }
-                else if (rel < (uint32_t)LHIST_BINS) atomicAdd(&lhist[rel], 1u);
+                if (rel < (uint32_t)LHIST_BINS) atomicAdd(&lhist[rel], 1u);
                 else atomicAdd(&hist[b], 1u);
             }
         }
@@ -515,7 +506,9 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window of the next frame
         }
-        __syncthreads();  // mags (lds) is reused by the next frame
+        // mags (lds) is reused by the next frame.  (Moving this barrier behind the next frame's register-only pass-1
+        // arithmetic, so that early waves do not idle here, costs 12 spilled VGPRs at 128 -- measured slower.)
+        __syncthreads();
     }
     if (have_base) {
         const uint32_t lbase = lhist_base;
@@ -528,31 +521,8 @@ __global__ __launch_bounds__(256, OCC) void stft8192_kernel(const float* __restr
 
 void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.tiles_c == 0) return;
-    static const int abl = getenv("BLISSGPU_ABL") ? atoi(getenv("BLISSGPU_ABL")) : 0;
-    static const int occ = getenv("BLISSGPU_STFT_OCC") ? atoi(getenv("BLISSGPU_STFT_OCC")) : 4;  // 4 workgroups/CU: 128 VGPRs, no spills (-6 % vs 3)
-#define LAUNCH_STFT(A) hipLaunchKernelGGL((stft8192_kernel<A, 3>), dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, \
-                                          b.pfx_c, t.hann8192, t.tw8192, w.spec, w.frame_max, w.h1, w.peak_rec, w.peak_cnt)
-    if (abl == 1) LAUNCH_STFT(1);
-    else if (abl == 2) LAUNCH_STFT(2);
-    else if (abl == 3) LAUNCH_STFT(3);
-    else if (abl == 4) LAUNCH_STFT(4);
-    else if (abl == 5) LAUNCH_STFT(5);
-    else if (abl == 6) LAUNCH_STFT(6);
-    else if (abl == 7) LAUNCH_STFT(7);
-    else if (abl == 8) LAUNCH_STFT(8);
-    else if (abl == 9) LAUNCH_STFT(9);
-    else if (abl == 11) LAUNCH_STFT(11);
-    else if (abl == 12) LAUNCH_STFT(12);
-    else if (abl == 13) LAUNCH_STFT(13);
-    else if (abl == 14) LAUNCH_STFT(14);
-    else if (abl == 15) LAUNCH_STFT(15);
-    else if (abl == 16) LAUNCH_STFT(16);
-    else if (abl == 17) LAUNCH_STFT(17);
-    else if (occ == 4)
-        hipLaunchKernelGGL((stft8192_kernel<0, 4>), dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs,
-                           b.pfx_c, t.hann8192, t.tw8192, w.spec, w.frame_max, w.h1, w.peak_rec, w.peak_cnt);
-    else LAUNCH_STFT(0);
-#undef LAUNCH_STFT
+    hipLaunchKernelGGL(stft8192_kernel, dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_c, t.hann8192,
+                       t.tw8192, w.spec, w.frame_max, w.h1, w.peak_rec, w.peak_cnt);
 }
 
 // ------------------------------------------------------------------------------------------------

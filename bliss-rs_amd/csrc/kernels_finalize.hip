@@ -22,47 +22,40 @@ __device__ __forceinline__ float normalize(float v, float mn, float mx) { return
 // executing ONE such chain still pays a full 4-cycle VALU issue per instruction, so the mapping is one LANE per
 // song: 64 songs advance their (independent) chains in lock step and a role costs 1/64 of the issue slots.
 //
-// Memory side: lane-per-song means 64 different streams, i.e. 64 different cache lines per load instruction if every
-// lane fetched its own stream.  Instead the wave stages the streams through LDS 64 elements at a time: for each of
-// its 64 songs it issues ONE coalesced 256-byte load (lane l fetches element base + l of song j; the song's base
-// pointer is a scalar read with v_readlane), the NEXT tile's 64 loads are in flight while the current tile is being
-// consumed, and every lane then walks its own row of the tile.  Rows are padded to 65 words, so both the row-wise
-// writes and the column-wise reads are bank-conflict free.
-constexpr int SEQ_TILE = 64;
+// Memory side: every lane streams its own series with 16-byte loads, 32 elements (eight loads) per step, and the NEXT
+// 32 elements are requested before the current ones are consumed: the ~100 cycles of dependent arithmetic per element
+// then cover the memory latency, and the kernel runs at the speed of its longest chain.  No LDS: the kernel must be
+// able to run beside the FFT-8192 kernel, whose four workgroups per CU leave 2 KB of LDS free.
+constexpr int SEQ_CHUNK = 32;
 
 template <typename T, typename Step>
-__device__ __forceinline__ void staged_for_each(const T* __restrict__ x, uint32_t n, T (*tile)[SEQ_TILE + 1], Step&& step) {
-    const int lane = threadIdx.x;
-    uint32_t n_max = n;
+__device__ __forceinline__ void seq_for_each(const T* __restrict__ x, uint32_t n, Step&& step) {
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    uint32_t i = 0;
+    while (i < n && ((reinterpret_cast<uintptr_t>(x + i) & 15) != 0)) { step(x[i], i); i++; }
+    const uint32_t n_chunks = (n - i) / SEQ_CHUNK;
+    v4 cur[SEQ_CHUNK / 4], nxt[SEQ_CHUNK / 4];
+    if (n_chunks) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, off, WAVE));
-    const uint64_t my_ptr = reinterpret_cast<uint64_t>(x);
-    T nxt[SEQ_TILE];
-    // one range-checked buffer load per song: lanes past the song's end read 0 (no exec masking, no clamping)
-    auto fetch = [&](uint32_t base) {
-        const uint32_t voff = (base + (uint32_t)lane) * 4u;
-#pragma unroll
-        for (int j = 0; j < SEQ_TILE; j++) {
-            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)my_ptr, j), hi = __builtin_amdgcn_readlane((uint32_t)(my_ptr >> 32), j);
-            const uint32_t nj = __builtin_amdgcn_readlane(n, j);
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, nj * 4u, 0x00020000);
-            const uint32_t raw = __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
-            __builtin_memcpy(&nxt[j], &raw, 4);
-        }
-    };
-    fetch(0);
-    for (uint32_t base = 0; base < n_max; base += SEQ_TILE) {
-#pragma unroll
-        for (int j = 0; j < SEQ_TILE; j++) tile[j][lane] = nxt[j];
-        __builtin_amdgcn_wave_barrier();
-        if (base + SEQ_TILE < n_max) fetch(base + SEQ_TILE);  // in flight while this tile is consumed
-        const uint32_t cnt = n > base ? (n - base < (uint32_t)SEQ_TILE ? n - base : (uint32_t)SEQ_TILE) : 0u;
-#pragma unroll 8
-        for (int e = 0; e < SEQ_TILE; e++)
-            if ((uint32_t)e < cnt) step(tile[lane][e], base + e);
-        __builtin_amdgcn_wave_barrier();
+        for (int u = 0; u < SEQ_CHUNK / 4; u++) cur[u] = *reinterpret_cast<const v4*>(x + i + 4 * u);
     }
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        if (c + 1 < n_chunks) {
+#pragma unroll
+            for (int u = 0; u < SEQ_CHUNK / 4; u++) nxt[u] = *reinterpret_cast<const v4*>(x + i + SEQ_CHUNK + 4 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < SEQ_CHUNK / 4; u++) {
+            step(cur[u].x, i + 4 * u);
+            step(cur[u].y, i + 4 * u + 1);
+            step(cur[u].z, i + 4 * u + 2);
+            step(cur[u].w, i + 4 * u + 3);
+        }
+#pragma unroll
+        for (int u = 0; u < SEQ_CHUNK / 4; u++) cur[u] = nxt[u];
+        i += SEQ_CHUNK;
+    }
+    for (; i < n; i++) step(x[i], i);
 }
 
 __device__ __forceinline__ void welford_step(float v, uint32_t i, float& mean, float& sum_sq) {
@@ -76,7 +69,7 @@ enum Role { R_CENT = 0, R_ROLL, R_FLAT, R_LOUD, R_ZCR, R_COUNT };
 
 // summary[s][0..15]: slots 1..9 = features 1..9 (zcr, centroid, rolloff, flatness, loudness)
 // grid = (ceil(n_songs / 64), R_COUNT): one wavefront = one role of 64 songs (lane = song).  A timbral role carries the
-// mean chain (one add per element) and the Welford chain of the same series: the series is staged once.
+// mean chain (one add per element) and the Welford chain of the same series: the series is streamed once.
 __global__ __launch_bounds__(64) void summary_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                      const float* __restrict__ centroid,
                                                      const float* __restrict__ rolloff,
@@ -84,9 +77,8 @@ __global__ __launch_bounds__(64) void summary_kernel(const SongDesc* __restrict_
                                                      const float* __restrict__ e256,
                                                      const uint32_t* __restrict__ zc256,
                                                      float* __restrict__ summary) {
-    __shared__ float tile[SEQ_TILE][SEQ_TILE + 1];
     const uint32_t s = blockIdx.x * 64 + threadIdx.x;
-    // lanes past the batch (or too-short songs) take part in the staging with n = 0
+    // lanes past the batch (or too-short songs) idle with n = 0
     SongDesc sd{};
     if (s < n_songs) sd = songs[s];
     const bool live = s < n_songs && sd.ok;
@@ -97,7 +89,7 @@ __global__ __launch_bounds__(64) void summary_kernel(const SongDesc* __restrict_
         const float* series = role == R_CENT ? centroid : (role == R_ROLL ? rolloff : flatness);
         const uint32_t n = live ? sd.n_t : 0u;
         float sum = 0.0f, mean = 0.0f, sum_sq = 0.0f;
-        staged_for_each(series + (live ? sd.t_off : 0), n, tile, [&](float v, uint32_t i) {
+        seq_for_each(series + (live ? sd.t_off : 0), n, [&](float v, uint32_t i) {
             sum += v;                            // utils::mean: sequential f32 sum
             welford_step(v, i, mean, sum_sq);    // ndarray std_axis
         });
@@ -117,7 +109,7 @@ __global__ __launch_bounds__(64) void summary_kernel(const SongDesc* __restrict_
         // sums of a chunk are added in order as they stream by
         const uint32_t n = live ? sd.n_e : 0u;
         float msum = 0.0f, mean = 0.0f, sum_sq = 0.0f, en = 0.0f;
-        staged_for_each(e256 + (live ? sd.e_off : 0), n, tile, [&](float v, uint32_t q) {
+        seq_for_each(e256 + (live ? sd.e_off : 0), n, [&](float v, uint32_t q) {
             en += v;
             if ((q & 3u) == 3u || q + 1 == n) {  // last block of chunk c = q / 4
                 const uint32_t c = q >> 2;
@@ -139,8 +131,7 @@ __global__ __launch_bounds__(64) void summary_kernel(const SongDesc* __restrict_
     } else {
         const uint32_t n = live ? sd.n_e : 0u;
         uint32_t c = 0;
-        staged_for_each(zc256 + (live ? sd.e_off : 0), n, reinterpret_cast<uint32_t(*)[SEQ_TILE + 1]>(tile),
-                        [&](uint32_t v, uint32_t) { c += v; });
+        seq_for_each(zc256 + (live ? sd.e_off : 0), n, [&](uint32_t v, uint32_t) { c += v; });
         if (live) feat[1] = normalize((float)c / (float)sd.n, 0.0f, 1.0f);
     }
 }

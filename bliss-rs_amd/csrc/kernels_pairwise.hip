@@ -123,7 +123,7 @@ __device__ __forceinline__ float unrolled_dot(FX xs, FY ys) {
 // quadratic form and the dot products unchanged, and both norm tables come from the same rows), so only the 256 x 256
 // blocks on or above the diagonal are computed; an off-diagonal block is also written transposed, 32 rows at a time
 // through an LDS tile so that the transposed stores are 128-byte runs.
-template <int D, int METRIC, bool DIAG, int ABL = 0, bool SYM = false>
+template <int D, int METRIC, bool DIAG, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restrict__ A, uint64_t n,
                                                        const float* __restrict__ B, uint64_t m,
                                                        const float* __restrict__ M, float* __restrict__ out,
@@ -235,8 +235,6 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
                 static_for<D - BODY>([&](auto kc) { sum = sum + term(std::integral_constant<int, BODY + decltype(kc)::value>{}); });
                 if (METRIC == METRIC_COSINE) {
                     q = splat(1.0f) - sum / (splat(sna[r]) * nb[h]);
-                } else if (ABL == 1) {
-                    q = sum;
                 } else {
                     q = sqrt_rn2(sum);
                 }
@@ -245,9 +243,7 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
             res[2 * h + 1] = q.y;
         }
         float* orow = out + (i0 + r) * ld_out + j0;
-        if (ABL == 2) {
-            if (res[0] == 123.456f || res[1] == 0.777f || res[2] == 3.25f || res[3] == 9.5f) orow[0] = 1.0f;
-        } else if (vec_ok) {
+        if (vec_ok) {
             typedef float f4 __attribute__((ext_vector_type(4)));
             f4 q4;
             q4.x = res[0]; q4.y = res[1]; q4.z = res[2]; q4.w = res[3];
@@ -337,24 +333,19 @@ template <int D>
 static void launch_d(const float* A, uint64_t n, const float* B, uint64_t m, int metric, const float* M, int diag,
                      float* out, uint64_t ld, hipStream_t st) {
     const dim3 grid((uint32_t)((m + PW_COLS - 1) / PW_COLS), (uint32_t)((n + PW_ROWS - 1) / PW_ROWS));
-    static const int abl = getenv("BLISSGPU_ABLPW") ? atoi(getenv("BLISSGPU_ABLPW")) : 0;
     static const bool no_sym = getenv("BLISSGPU_PW_NOSYM") != nullptr;  // developer aid: force the general kernel
-    if (A == B && n == m && abl == 0 && !no_sym) {  // self-distance matrix: upper block triangle + mirrored stores
+    if (A == B && n == m && !no_sym) {  // self-distance matrix: upper block triangle + mirrored stores
         if (metric == METRIC_EUCLIDEAN)
-            hipLaunchKernelGGL((pairwise_kernel<D, METRIC_EUCLIDEAN, false, 0, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
+            hipLaunchKernelGGL((pairwise_kernel<D, METRIC_EUCLIDEAN, false, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
         else if (metric == METRIC_COSINE)
-            hipLaunchKernelGGL((pairwise_kernel<D, METRIC_COSINE, false, 0, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
+            hipLaunchKernelGGL((pairwise_kernel<D, METRIC_COSINE, false, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
         else if (diag)
-            hipLaunchKernelGGL((pairwise_kernel<D, METRIC_MAHALANOBIS, true, 0, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
+            hipLaunchKernelGGL((pairwise_kernel<D, METRIC_MAHALANOBIS, true, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
         else
-            hipLaunchKernelGGL((pairwise_kernel<D, METRIC_MAHALANOBIS, false, 0, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
+            hipLaunchKernelGGL((pairwise_kernel<D, METRIC_MAHALANOBIS, false, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
         return;
     }
-    if (metric == METRIC_EUCLIDEAN && abl == 1)
-        hipLaunchKernelGGL((pairwise_kernel<D, METRIC_EUCLIDEAN, false, 1>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
-    else if (metric == METRIC_EUCLIDEAN && abl == 2)
-        hipLaunchKernelGGL((pairwise_kernel<D, METRIC_EUCLIDEAN, false, 2>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
-    else if (metric == METRIC_EUCLIDEAN)
+    if (metric == METRIC_EUCLIDEAN)
         hipLaunchKernelGGL((pairwise_kernel<D, METRIC_EUCLIDEAN, false>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
     else if (metric == METRIC_COSINE)
         hipLaunchKernelGGL((pairwise_kernel<D, METRIC_COSINE, false>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);

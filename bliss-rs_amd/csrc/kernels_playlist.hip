@@ -245,7 +245,24 @@ struct PairArgs { float a[PL_DMAX]; float b[PL_DMAX]; };
 
 __global__ __launch_bounds__(64) void pair_distance_kernel(PairArgs p, uint32_t d, int metric, const float* __restrict__ M,
                                                            float* __restrict__ out) {
-    if (threadIdx.x == 0) *out = pl_distance(p.a, p.b, d, metric, M);
+    __shared__ float sa[PL_DMAX], sb[PL_DMAX], st[PL_DMAX];
+    const uint32_t tid = threadIdx.x;
+    sa[tid] = p.a[tid];
+    sb[tid] = p.b[tid];
+    __syncthreads();
+    if (metric != PL_MAHALANOBIS) {
+        if (tid == 0) *out = pl_distance(sa, sb, d, metric, M);
+        return;
+    }
+    // (a - b) . M: column jj is an independent sequential sum over ii (Array1.dot(Array2) walks each column in order), so
+    // the d columns go to d lanes; the final unrolled_dot stays on one lane.  Same operations, same order as pl_distance.
+    if (tid < d) {
+        float acc = 0.0f;
+        for (uint32_t ii = 0; ii < d; ii++) acc = acc + (sa[ii] - sb[ii]) * M[ii * d + tid];
+        st[tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) *out = sqrtf(pl_udot([&](uint32_t k) { return st[k]; }, [&](uint32_t k) { return sa[k] - sb[k]; }, d));
 }
 
 void launch_pair_distance(const float* a, const float* b, uint32_t d, int metric, const float* d_M, float* out, hipStream_t st) {

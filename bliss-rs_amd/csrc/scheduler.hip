@@ -11,10 +11,12 @@
 //   feed      host PCM (f32 or s16, mono or interleaved multi-channel) is shipped group by group into two device
 //             buffers, the copy of group g + 1 overlapping the analysis of group g;
 //   front     concurrent single-song calls (N worker threads each calling Song::analyze, src/song/decoder.rs:299-329)
-//             are coalesced: whoever holds the run lock analyses every request that queued up behind it as ONE batch.
+//             are coalesced: whoever finds no batch running analyses every request that has queued up as ONE batch.
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <numeric>
 
 #include "ctx.hpp"
@@ -347,8 +349,9 @@ int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t*
 // ------------------------------------------------------------------------------------------------------------------
 // Coalescing front of the single-song entry points.  The reference's bulk path is N worker threads each calling
 // Song::analyze on its own song (src/song/decoder.rs:299-329); one song cannot fill the GPU, a batch can.  A caller
-// queues its request and takes the run lock; whoever holds the lock analyses EVERYTHING that queued up behind it as one
-// batch (group commit).  A lone caller pays no waiting window; under load the batch size adapts to the arrival rate.
+// queues its request; whoever finds no batch running becomes the leader and analyses EVERYTHING that has queued up as
+// one batch (group commit), the others sleep until their request is done.  A lone caller pays no waiting window; under
+// load the batch size adapts to the arrival rate.
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -364,55 +367,74 @@ struct AnalyzeReq {
     bool done = false;
 };
 
-std::mutex g_q_mu;
+// One mutex, two condition variables: `arrive` wakes a leader that is gathering its batch, `done` wakes the callers whose
+// requests a leader has finished.  Whoever finds no batch running becomes the leader and takes the whole queue.
+std::mutex g_mu;
+std::condition_variable g_cv_arrive, g_cv_done;
 std::vector<AnalyzeReq*> g_queue;
-std::mutex g_run_mu;
+bool g_running = false;
+size_t g_last_batch = 1;
 
-int submit(AnalyzeReq& r, const char* who) {
-    { std::lock_guard<std::mutex> lk(g_q_mu); g_queue.push_back(&r); }
-    std::vector<AnalyzeReq*> take;
-    {
-        std::lock_guard<std::mutex> run(g_run_mu);
-        {
-            std::lock_guard<std::mutex> lk(g_q_mu);
-            if (!r.done) take.swap(g_queue);  // r itself is in there: it was queued before the run lock was taken
-        }
-        if (!take.empty()) {
-            blissgpu_ctx* c = nullptr;
-            int rc0 = default_ctx(&c);
-            // one device batch per (sample format, channels, features version) class; in practice there is one class
-            std::vector<char> served(take.size(), 0);
-            for (size_t a = 0; a < take.size(); a++) {
-                if (served[a]) continue;
-                std::vector<size_t> cls;
-                for (size_t q = a; q < take.size(); q++)
-                    if (!served[q] && take[q]->bytes_per_sample == take[a]->bytes_per_sample &&
-                        take[q]->channels == take[a]->channels && take[q]->version == take[a]->version) {
-                        cls.push_back(q);
-                        served[q] = 1;
-                    }
-                const uint32_t d = blissgpu_feature_count(take[a]->version);
-                std::vector<const void*> ptrs(cls.size());
-                std::vector<uint64_t> lens(cls.size());
-                std::vector<int32_t> st(cls.size(), 0);
-                std::vector<float> rows(cls.size() * (size_t)std::max(d, 1u));
-                for (size_t q = 0; q < cls.size(); q++) { ptrs[q] = take[cls[q]]->pcm; lens[q] = take[cls[q]]->frames; }
-                int rc = rc0 ? rc0
-                             : analyze_host_songs(c, ptrs.data(), lens.data(), (uint32_t)cls.size(), take[a]->bytes_per_sample,
-                                                  take[a]->channels, take[a]->version, rows.data(), st.data(), who);
-                const std::string err = rc ? blissgpu_last_error() : "";
-                for (size_t q = 0; q < cls.size(); q++) {
-                    AnalyzeReq* t = take[cls[q]];
-                    t->rc = rc;
-                    t->err = err;
-                    t->status = st[q];
-                    if (!rc) memcpy(t->out, rows.data() + q * d, d * sizeof(float));
-                }
+void run_batch(std::vector<AnalyzeReq*>& take, const char* who) {
+    blissgpu_ctx* c = nullptr;
+    const int rc0 = default_ctx(&c);
+    // one device batch per (sample format, channels, features version) class; in practice there is one class
+    std::vector<char> served(take.size(), 0);
+    for (size_t a = 0; a < take.size(); a++) {
+        if (served[a]) continue;
+        std::vector<size_t> cls;
+        for (size_t q = a; q < take.size(); q++)
+            if (!served[q] && take[q]->bytes_per_sample == take[a]->bytes_per_sample &&
+                take[q]->channels == take[a]->channels && take[q]->version == take[a]->version) {
+                cls.push_back(q);
+                served[q] = 1;
             }
-            std::lock_guard<std::mutex> lk(g_q_mu);
-            for (AnalyzeReq* t : take) t->done = true;
+        const uint32_t d = blissgpu_feature_count(take[a]->version);
+        std::vector<const void*> ptrs(cls.size());
+        std::vector<uint64_t> lens(cls.size());
+        std::vector<int32_t> st(cls.size(), 0);
+        std::vector<float> rows(cls.size() * (size_t)std::max(d, 1u));
+        for (size_t q = 0; q < cls.size(); q++) { ptrs[q] = take[cls[q]]->pcm; lens[q] = take[cls[q]]->frames; }
+        const int rc = rc0 ? rc0
+                           : analyze_host_songs(c, ptrs.data(), lens.data(), (uint32_t)cls.size(), take[a]->bytes_per_sample,
+                                                take[a]->channels, take[a]->version, rows.data(), st.data(), who);
+        const std::string err = rc ? blissgpu_last_error() : "";
+        for (size_t q = 0; q < cls.size(); q++) {
+            AnalyzeReq* t = take[cls[q]];
+            t->rc = rc;
+            t->err = err;
+            t->status = st[q];
+            if (!rc) memcpy(t->out, rows.data() + q * d, d * sizeof(float));
         }
     }
+}
+
+int submit(AnalyzeReq& r, const char* who) {
+    std::unique_lock<std::mutex> lk(g_mu);
+    g_queue.push_back(&r);
+    g_cv_arrive.notify_one();
+    while (!r.done) {
+        if (g_running) {
+            g_cv_done.wait(lk);
+            continue;
+        }
+        g_running = true;
+        // The callers the previous batch released are on their way back with their next song: when that batch showed
+        // there is company, give them a moment (at most 200 us against a batch of milliseconds) instead of running a
+        // batch of one.  A lone caller never waits.
+        if (g_last_batch > 1)
+            g_cv_arrive.wait_for(lk, std::chrono::microseconds(200), [&] { return g_queue.size() >= g_last_batch; });
+        std::vector<AnalyzeReq*> take;
+        take.swap(g_queue);
+        g_last_batch = take.size();
+        lk.unlock();
+        run_batch(take, who);
+        lk.lock();
+        for (AnalyzeReq* t : take) t->done = true;
+        g_running = false;
+        g_cv_done.notify_all();
+    }
+    lk.unlock();
     if (r.rc) return fail(r.rc, who, r.err.c_str());
     return BLISSGPU_OK;
 }

@@ -29,7 +29,7 @@ struct RawS16Decoder : Decoder {  // ffmpeg's s16 -> flt conversion: sample / 32
 };
 
 int main(int argc, char** argv) {
-    CHECK(argc == 3);
+    CHECK(argc == 3 || argc == 4);
     // test_analysis_too_small (src/song/mod.rs:539-551)
     try { Song::analyze({0.0f}); CHECK(false); } catch (const BlissError& e) { CHECK(e == AnalysisError("empty or too short song.")); }
     try { Song::analyze({}); CHECK(false); } catch (const BlissError& e) { CHECK(e == AnalysisError("empty or too short song.")); }
@@ -51,6 +51,21 @@ int main(int argc, char** argv) {
         auto r = analyze_batch(std::vector<std::vector<int16_t>>{s16, std::vector<int16_t>(10, 0)});
         CHECK(std::get<Analysis>(r[0]) == song.analysis);
         CHECK(std::get<BlissError>(r[1]) == AnalysisError("empty or too short song."));
+    }
+    // stereo decoder output: the mono downmix runs on the device ((L + R) * SQRT_2 / 2, src/song/decoder/symphonia.rs:281-285)
+    if (argc == 4) {
+        std::ifstream f(argv[3], std::ios::binary);
+        std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        std::vector<int16_t> st(raw.size() / 2);
+        std::memcpy(st.data(), raw.data(), st.size() * 2);
+        std::vector<float> mono(st.size() / 2);
+        for (size_t i = 0; i < mono.size(); i++) {
+            const float l = (float)st[2 * i] / 32768.0f, r = (float)st[2 * i + 1] / 32768.0f;
+            volatile float sum = l + r;               // every step rounds to f32, like the Rust expression
+            volatile float scaled = sum * 1.41421356237309504880f;
+            mono[i] = scaled / 2.0f;
+        }
+        CHECK(Song::analyze_interleaved(st, 2) == Song::analyze(mono));
     }
     // bulk path: a missing file is reported, not fatal (src/song/decoder.rs:313-325)
     auto res = dec.analyze_paths({argv[1], "/nonexistent.raw"});

@@ -529,6 +529,8 @@ def test_cpp_host_mirror(tmp_path, literals):
     load_golden("s16_mono_22_5kHz.pcm_s16.npy").astype("<i2").tofile(raw)
     exp = tmp_path / "expected.txt"
     exp.write_text(" ".join(repr(v) for v in literals["analysis_v2_s16_mono_22_5kHz"]["values"]))
-    out = subprocess.run([str(exe), str(raw), str(exp)], capture_output=True, text=True, timeout=300)
+    stereo = tmp_path / "stereo.s16"
+    load_golden("s16_stereo_22_5kHz.pcm_s16.npy").astype("<i2").tofile(stereo)
+    out = subprocess.run([str(exe), str(raw), str(exp), str(stereo)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout
