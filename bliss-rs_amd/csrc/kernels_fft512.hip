@@ -208,6 +208,9 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
 
     float ss_acc = 0.0f;    // per-lane partial sums of the current 256-sample block
     uint32_t zc_acc = 0;
+    // reduced sums of the timbral frame this lane will finish (see finish16)
+    float st_total = 0.0f, st_wtotal = 0.0f, st_mant = 1.0f;
+    int st_ints = 0;
     const float freq_per_bin = (float)SAMPLE_RATE / (float)W512;
 
     // one frame of the unrolled body: J = position in the body (k = kb + J), CUR / PREV = the magnitude sets as above
@@ -246,35 +249,32 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
         if (k < (long)sd.n_t) {
             // the 256-bin vector the reference's timbral path sees: bin 255 := |Re X[256]| (src/aubio.rs:240-261)
             const float m15 = (l == 15) ? cur.nyq : cur.m[15];
-            float sum = 0.0f, wsum = 0.0f, sqsum = 0.0f;
+            // sum m, sum e m (e = bin index inside the lane) and sum m^2, two bins per packed instruction
+            f2 s2 = mk(0.0f, 0.0f), e2 = mk(0.0f, 0.0f), q2 = mk(0.0f, 0.0f);
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const float me = e == 15 ? m15 : cur.m[e];
-                sum += me;
-                wsum += (float)(16 * l + e) * me;
-                sqsum += me * me;
+            for (int i = 0; i < 8; i++) {
+                const f2 mp = mk(cur.m[2 * i], i == 7 ? m15 : cur.m[2 * i + 1]);
+                s2 = s2 + mp;
+                e2 = e2 + mp * mk((float)(2 * i), (float)(2 * i + 1));
+                q2 = q2 + mp * mp;
             }
+            const float sum = s2.x + s2.y, sqsum = q2.x + q2.y;
+            const float wsum = (float)(16 * l) * sum + (e2.x + e2.y);  // sum (16 l + e) m_e
             const float total = row16_sum(sum);
             const float wtotal = row16_sum(wsum);
-            // spectral_centroid (src/aubio.rs:16-29) then bin_to_freq (:68-71)
-            const float cbin = (total == 0.0f) ? 0.0f : wtotal / total;
             // spectral_rolloff (src/aubio.rs:36-58): bins consumed until the running energy reaches 95 %
             const float incl = row16_scan_incl(sqsum);
             const float cum_total = row16_sum(sqsum);
-            float rbin = 0.0f;
-            if (cum_total != 0.0f) {
-                const float thr = cum_total * 0.95f;
-                float run = incl - sqsum;
-                int below = 0;
+            const float thr = cum_total * 0.95f;
+            float run = incl - sqsum;
+            int below = 0;
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const float me = e == 15 ? m15 : cur.m[e];
-                    run += me * me;
-                    below += (run < thr) ? 1 : 0;
-                }
-                const int c = row16_sum(below);
-                rbin = (float)((c < 256) ? c + 1 : 256);
+            for (int e = 0; e < 16; e++) {
+                const float me = e == 15 ? m15 : cur.m[e];
+                run += me * me;
+                below += (run < thr) ? 1 : 0;
             }
+            const int c = row16_sum(below);
             // geometric_mean (src/utils.rs:101-117): groups of 8 in f64, exponents and mantissas apart
             int expo = 0, zero = 0;
             double mant = 1.0;
@@ -294,16 +294,34 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
             const int exps = row16_sum(expo);
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) mant *= __shfl_xor(mant, off, 16);
+            // The scalar tail (two divisions, log2, exp2, the normalisations: ~40 instructions) would run identically on all
+            // 16 lanes of the group; instead lane k mod 16 keeps the reduced sums of frame k and every 16 frames each lane
+            // finishes ITS frame -- one pass of the scalar tail serves 16 frames, and the three stores become coalesced.
+            const bool mine = l == ((int)k & 15);
+            // packed integers: rolloff count (9 bits) | any zero group (bit 9) | zero energy (bit 10) | exponent sum (from bit 11)
+            const int packed = c | (any_zero ? 1 << 9 : 0) | (cum_total == 0.0f ? 1 << 10 : 0) | (exps << 11);
+            st_total = mine ? total : st_total;
+            st_wtotal = mine ? wtotal : st_wtotal;
+            st_ints = mine ? packed : st_ints;
+            st_mant = mine ? (float)mant : st_mant;
+        }
+    };
+    // finish the frames [k16, k16 + 16) whose sums the lanes hold (lane l: frame k16 + l)
+    auto finish16 = [&](long k16) {
+        const long k = k16 + l;
+        if (k < k_end && k < (long)sd.n_t) {
+            // spectral_centroid (src/aubio.rs:16-29) then bin_to_freq (:68-71)
+            const float cbin = (st_total == 0.0f) ? 0.0f : st_wtotal / st_total;
+            const int st_c = st_ints & 511, st_exps = st_ints >> 11;
+            const float rbin = (st_ints & (1 << 10)) ? 0.0f : (float)((st_c < 256) ? st_c + 1 : 256);
             float flat = 0.0f;
-            if (!any_zero) {
-                const float geo = exp2f((log2f((float)mant) + (float)exps) / 256.0f - (1023.0f + 500.0f) / 8.0f);
-                if (geo != 0.0f) flat = geo / (total / 256.0f);
+            if (!(st_ints & (1 << 9))) {
+                const float geo = exp2f((log2f(st_mant) + (float)st_exps) / 256.0f - (1023.0f + 500.0f) / 8.0f);
+                if (geo != 0.0f) flat = geo / (st_total / 256.0f);
             }
-            if (l == 0) {
-                centroid[sd.t_off + k] = freq_per_bin * fmaxf(cbin, 0.0f);
-                rolloff[sd.t_off + k] = freq_per_bin * fmaxf(rbin, 0.0f);
-                flatness[sd.t_off + k] = flat;
-            }
+            centroid[sd.t_off + k] = freq_per_bin * fmaxf(cbin, 0.0f);
+            rolloff[sd.t_off + k] = freq_per_bin * fmaxf(rbin, 0.0f);
+            flatness[sd.t_off + k] = flat;
         }
     };
 
@@ -315,6 +333,8 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
         if (kb + 2 < k_end) frame(std::integral_constant<int, 2>{}, kb + 2, A, B);
         __builtin_amdgcn_sched_barrier(0);
         if (kb + 3 < k_end) frame(std::integral_constant<int, 3>{}, kb + 3, A, B);
+        __builtin_amdgcn_sched_barrier(0);
+        if ((kb & 15) == 12 || kb + 4 >= k_end) finish16(kb & ~15L);  // 16 frames stashed, or the group's last frames
     }
 
     // ---- the samples no FFT frame brings in: [128 n_f, n), 256 .. 511 of them, handled by the group that owns the
