@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Tool-side (not bench) parity check of EVERY song of the default bench batch: the 1024 synthetic 3-minute songs of
+configs[1] analysed on the GPU against the CPU oracle (all host cores, ~40 s).  Prints one JSON line.
+
+    python tests/tools/full_check.py [--songs 1024] [--threads 64]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--songs", type=int, default=1024)
+    ap.add_argument("--samples", type=int, default=3969000)
+    ap.add_argument("--threads", type=int, default=64)
+    args = ap.parse_args()
+    import torch
+
+    import bliss_rs_amd as bliss
+    import oracle as O
+
+    n, N = args.songs, args.samples
+    ctx = bliss.Context(0)
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(N)
+    lens = np.full(n, N, np.uint64)
+    pcm = torch.empty(n * N, dtype=torch.float32, device="cuda")
+    ctx.synth_white_noise(pcm, offs, lens, first_song_index=0)
+    out, status = ctx.analyze(pcm, offs, lens, 2)
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    tuning, _ = ctx.last_tuning(n)
+    t0 = time.perf_counter()
+    ref = np.empty((n, 23), np.float32)
+    step = 128  # bounded host memory: 128 songs = 2 GB of PCM at a time
+    for i0 in range(0, n, step):
+        k = min(step, n - i0)
+        host = pcm[i0 * N:(i0 + k) * N].cpu().numpy()
+        r, st = O.song_analyze_batch(host, np.arange(k, dtype=np.uint64) * np.uint64(N), np.full(k, N, np.uint64), 2,
+                                     min(args.threads, k))
+        assert (st == 0).all()
+        ref[i0:i0 + k] = r
+    err = np.abs(got - ref)
+    res = {"songs": n, "samples_per_song": N, "oracle_seconds": round(time.perf_counter() - t0, 1),
+           "max_abs_err_non_tempo": float(err[:, 1:].max()),
+           "max_abs_err_per_feature": [float(x) for x in err.max(axis=0)],
+           "songs_over_1e-5_non_tempo": int((err[:, 1:].max(axis=1) > 1e-5).sum()),
+           "tempo_mismatches_over_1e-4": int((err[:, 0] > 1e-4).sum()),
+           "max_abs_err_tempo": float(err[:, 0].max()),
+           "status_all_ok": bool((status.cpu().numpy() == 0).all())}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
