@@ -120,7 +120,7 @@ struct blissgpu_ctx {
     bg::DeviceTables tables{};
     // analysis
     bg::ChunkSlot slot[2];
-    uint64_t chunk_seq = 0;            // chunks run so far (slot = chunk_seq & 1)
+    uint64_t chunk_seq = 0;            // chunks run so far
     bg::DevBuf<int32_t> dbg_tuning;
     bg::DevBuf<uint32_t> dbg_nbpms;
     uint32_t dbg_n = 0;

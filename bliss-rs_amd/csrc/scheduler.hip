@@ -520,8 +520,9 @@ int blissgpu_analyze_batch_device(blissgpu_ctx* c, const float* d_pcm, const uin
     while (!todo.empty()) {
         const Range r = todo.back();
         todo.pop_back();
-        ChunkSlot& slot = c->slot[c->chunk_seq & 1];
-        // the slot's own back half (chunk k - 2) is always enqueued by now; its front may only follow it
+        // Every call starts with slot 0, so a batch that fits one chunk never allocates the second slot.  The slot's own
+        // back half (chunk k - 2, or the previous call's) is always enqueued by now; its front may only follow it.
+        ChunkSlot& slot = c->slot[chunks & 1];
         rc = chunk_front(c, slot, d_pcm, songs.data() + r.b, r.e - r.b);
         if (rc == BLISSGPU_ERR_OOM && r.e - r.b > 1) {
             // the device has less free memory than the limit assumed (another process, the caller's own tensors):

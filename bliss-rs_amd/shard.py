@@ -34,34 +34,37 @@ def all_gather_features(local_rows, local_indices, n_total: int, group=None, n_l
     local_rows: torch tensor [n_local, d] (CUDA -> RCCL, CPU -> gloo); local_indices: global song index
     of each local row.  Returns a [n_total, d] tensor on the same device, identical on every rank.
     n_local_max: the largest shard size if the caller knows it (e.g. from shard_songs, which every rank computes
-    identically); it saves the count exchange and its host synchronisation."""
+    identically); it saves the count exchange and its host synchronisation.
+
+    ONE collective per call: the global row index travels as an extra column of the row itself (song counts stay far
+    below 2^24, so an f32 column holds them exactly), the blocks are padded to the largest shard (<= ~1 MB per rank at
+    library sizes: latency-bound on xGMI), and one index_copy scatters all ranks' rows at once -- no host
+    synchronisation, no per-rank loop."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    d = local_rows.shape[1]
+    n_local, d = local_rows.shape
     dev = local_rows.device
+    assert n_total < (1 << 24), "row indices travel as f32"
     idx = local_indices.to(dev) if torch.is_tensor(local_indices) else torch.as_tensor(np.asarray(local_indices, dtype=np.int64), device=dev)
     if n_local_max is None:
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(counts, torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=dev), group=group)
-        n_max = int(max(int(c.item()) for c in counts))
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(counts, torch.tensor([n_local], dtype=torch.int64, device=dev), group=group)
+        n_max = int(counts.max().item())
     else:
         n_max = int(n_local_max)
-        assert local_rows.shape[0] <= n_max
-    # pad to the largest shard: one fixed-size all-gather (latency-bound at these sizes: <= ~1 MB)
-    pad_rows = torch.zeros((n_max, d), dtype=local_rows.dtype, device=dev)
-    pad_rows[: local_rows.shape[0]] = local_rows
-    pad_idx = torch.full((n_max,), -1, dtype=torch.int64, device=dev)
-    pad_idx[: idx.shape[0]] = idx
-    rows = [torch.empty_like(pad_rows) for _ in range(world)]
-    idxs = [torch.empty_like(pad_idx) for _ in range(world)]
-    dist.all_gather(rows, pad_rows, group=group)
-    dist.all_gather(idxs, pad_idx, group=group)
-    # scatter without a host synchronisation: padding rows (index -1) land in one spare row past the end
+        assert n_local <= n_max
+    pack = torch.zeros((n_max, d + 1), dtype=local_rows.dtype, device=dev)
+    pack[:, d] = -1.0                                  # padding rows
+    pack[:n_local, :d] = local_rows
+    pack[:n_local, d] = idx.to(local_rows.dtype)
+    gathered = torch.empty((world * n_max, d + 1), dtype=local_rows.dtype, device=dev)
+    dist.all_gather_into_tensor(gathered, pack, group=group)
+    rows = gathered[:, d].to(torch.int64)
+    rows = torch.where(rows < 0, torch.full_like(rows, n_total), rows)   # padding lands in one spare row past the end
     full = torch.full((n_total + 1, d), float("nan"), dtype=local_rows.dtype, device=dev)
-    for r, i in zip(rows, idxs):
-        full.index_copy_(0, torch.where(i < 0, torch.full_like(i, n_total), i), r)
+    full.index_copy_(0, rows, gathered[:, :d])
     return full[:n_total]
 
 

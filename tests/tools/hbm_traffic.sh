@@ -3,7 +3,7 @@
 # one pass on gfx950), kernel-trace only.  usage (GPU box): SONGS=256 bash tests/tools/hbm_traffic.sh
 R=$PWD; cd /tmp; export TMPDIR=/tmp; export BLISSGPU_SERIAL=1
 S=${SONGS:-256}
-B="python $R/bench.py --songs $S --steps 1 --warmup 1 --no-cpu-baseline --no-pairwise --no-host-feed"
+B="python $R/bench.py --songs $S --steps 1 --warmup 1 --no-cpu-baseline --no-pairwise --no-host-feed --no-small-calls"
 rm -rf $R/gpurun_out/hbm
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do

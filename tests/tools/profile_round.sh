@@ -1,14 +1,20 @@
 #!/bin/bash
-# Round-end evidence on the GPU box: (1) the default bench line, (2) rocprofv3 --kernel-trace --stats of the
-# same command, (3) HBM traffic (separate FETCH_SIZE / WRITE_SIZE --pmc passes).  Outputs under gpurun_out/round/;
-# copy the summaries into profiles/ afterwards.   usage: TAG=r01 bash tests/tools/profile_round.sh
-R=$PWD; TAG=${TAG:-r01}; O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
-python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 600 $O/bench.json
+# Round-end evidence on the GPU box: (1) the default bench line and the mixed / library configurations, (2) rocprofv3
+# --kernel-trace --stats of the default bench command, (3) HBM traffic (separate FETCH_SIZE / WRITE_SIZE --pmc passes),
+# (4) the SQ counter passes of the two FFT kernels.  Outputs under gpurun_out/round/; copy the summaries into profiles/.
+#   usage: TAG=r02 bash tests/tools/profile_round.sh
+R=$PWD; TAG=${TAG:-r02}; O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
+python bench.py > $O/${TAG}_bench_batch.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 400 $O/${TAG}_bench_batch.json; echo
+python bench.py --config mixed --steps 2 --warmup 1 > $O/${TAG}_bench_mixed.json 2> $O/bench_mixed.err; echo "mixed rc=$?"; head -c 300 $O/${TAG}_bench_mixed.json; echo
+python bench.py --config library --steps 2 --warmup 1 > $O/${TAG}_bench_library.json 2> $O/bench_library.err; echo "library rc=$?"; head -c 300 $O/${TAG}_bench_library.json; echo
 cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py --no-cpu-baseline --no-host-feed --no-playlist > $O/trace.log 2>&1; echo "trace rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py --no-cpu-baseline --no-host-feed --no-playlist --no-small-calls > $O/trace.log 2>&1; echo "trace rc=$?"
 cd $R
 DB=$(find $O/trace -name "*.db" | head -1)
 python tests/tools/rocpd_stats.py $DB > $O/${TAG}_bench_1024songs.kernel_stats.txt; head -16 $O/${TAG}_bench_1024songs.kernel_stats.txt
 rm -rf $O/trace
 SONGS=${HBM_SONGS:-256} bash tests/tools/hbm_traffic.sh > $O/hbm.log 2>&1; tail -16 $O/hbm.log
-cp gpurun_out/hbm/hbm_traffic.json gpurun_out/hbm/hbm_traffic.txt $O/ 2>/dev/null
+cp gpurun_out/hbm/hbm_traffic.json $O/hbm_traffic.json; cp gpurun_out/hbm/hbm_traffic.txt $O/${TAG}_hbm_traffic_256songs.txt
+for K in stft8192 fft512; do
+  KRE=$K bash tests/tools/pmc_one.sh 2>&1 | grep -v amdgpu.ids > $O/${TAG}_pmc_${K}.txt; tail -18 $O/${TAG}_pmc_${K}.txt
+done
