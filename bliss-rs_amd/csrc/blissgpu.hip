@@ -160,6 +160,7 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
     if (se == hipSuccess) se = hipHostMalloc((void**)&c->h_scalar, 64, hipHostMallocDefault);
     if (se != hipSuccess) { blissgpu_ctx_destroy(c); return fail(BLISSGPU_ERR_HIP, "aux stream/events", hipGetErrorString(se)); }
     if (const char* e = getenv("BLISSGPU_SERIAL")) c->serial = (e[0] == '1');
+    if (const char* e = getenv("BLISSGPU_TAIL_MODE")) c->tail_mode = atoi(e);
     if (const char* e = getenv("BLISSGPU_PIPELINE_CHUNKS")) c->pipeline_chunks = (uint32_t)std::min(64, std::max(1, atoi(e)));
     // developer / test aid: slots per chroma frame of the tuning-candidate pool (0 forces the re-scan path of tune_final_kernel)
     if (const char* e = getenv("BLISSGPU_CAND_BUDGET")) c->cand_budget = (uint32_t)std::max(0, atoi(e));

@@ -107,6 +107,8 @@ struct blissgpu_ctx {
     hipStream_t stream = nullptr;      // FFT + chroma chain (the caller-visible stream)
     hipStream_t aux_stream = nullptr;  // per-song tails: PCM statistics, summaries, beat tracker, row assembly
     hipStream_t chr_stream = nullptr;  // tuning estimate of a chunk, beside the next chunk's FFT kernels
+    int tail_mode = -1;                // beat tracker: -1 = beside the FFT-8192 kernel unless the batch is one chunk, 0 / 1 force
+                                       // beside / behind it (BLISSGPU_TAIL_MODE, developer aid)
     uint32_t pipeline_chunks = 1;      // cut big batches into at least this many chunks (BLISSGPU_PIPELINE_CHUNKS; measured: the
                                        // per-song tails have a fixed latency per launch, so more chunks than memory needs lose)
     hipEvent_t ev_interop = nullptr;

@@ -111,7 +111,7 @@ int ensure_slot_events(ChunkSlot& s) {
 // The back half of chunk k is enqueued AFTER the front half of chunk k + 1: the latency-bound tuning kernels of chunk k
 // then hide beside chunk k + 1's FFT kernels instead of sitting between the FFT-8192 kernel and the contraction.
 // Nothing here waits for the device except the reuse of a slot's pinned descriptor staging and buffer growth.
-int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* songs, uint32_t ns) {
+int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* songs, uint32_t ns, bool only_chunk) {
     int rc = ensure_slot_events(slot);
     if (rc) return rc;
     // ---- offsets into the batch-wide series + tile prefixes ----
@@ -191,12 +191,20 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
         HIP_TRY(hipStreamWaitEvent(sb, slot.ev_fork, 0));
     }
     { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
-    { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
+    // The beat tracker is one 256-thread workgroup per song: beside the FFT-8192 kernel every one of them displaces an
+    // FFT-8192 workgroup (that kernel fills the LDS and the register file).  In a multi-chunk batch that is still the
+    // best place (measured on the 6 250-song mixed corpus: 452 vs 472 ms) -- everything later belongs to the next chunk;
+    // a batch of ONE chunk runs it behind the FFT-8192 kernel, beside the tuning / chroma kernels (42.6 vs 43.0 ms per
+    // 1024 songs, and the FFT-8192 kernel keeps its undisturbed 18 ms).
+    const bool beat_late = c->tail_mode == 1 || (c->tail_mode < 0 && only_chunk);
+    if (!beat_late) { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
     { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st); }
     if (multi) {
         HIP_TRY(hipEventRecord(slot.ev_stft, st));
         HIP_TRY(hipStreamWaitEvent(sc, slot.ev_stft, 0));
+        if (beat_late) HIP_TRY(hipStreamWaitEvent(sb, slot.ev_stft, 0));
     }
+    if (beat_late) { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
     { Prof p(c, K_TUNE_SELECT, sc); launch_tune_select(b, w, sc); }
     { Prof p(c, K_TUNE_PASS2, sc); launch_tune_pass2(b, w, sc); }
     { Prof p(c, K_TUNE_FINAL, sc); launch_tune_final(b, w, sc); }
@@ -523,7 +531,7 @@ int blissgpu_analyze_batch_device(blissgpu_ctx* c, const float* d_pcm, const uin
         // Every call starts with slot 0, so a batch that fits one chunk never allocates the second slot.  The slot's own
         // back half (chunk k - 2, or the previous call's) is always enqueued by now; its front may only follow it.
         ChunkSlot& slot = c->slot[chunks & 1];
-        rc = chunk_front(c, slot, d_pcm, songs.data() + r.b, r.e - r.b);
+        rc = chunk_front(c, slot, d_pcm, songs.data() + r.b, r.e - r.b, chunks == 0 && todo.empty());
         if (rc == BLISSGPU_ERR_OOM && r.e - r.b > 1) {
             // the device has less free memory than the limit assumed (another process, the caller's own tensors):
             // halve the chunk and go on
