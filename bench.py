@@ -74,8 +74,10 @@ def oracle_mod():
 
 def cpu_baseline(global_indices, lengths, features_version=2):
     """The oracle (C restatement of the reference algorithm, oracle/) on the host cores: the same white-noise songs
-    (bit-identical generator), one song per thread at a time.  Two thread counts are timed (the port is memory-bound
-    well before it runs out of cores) and the better one is reported, with the thread count it used.  This is a PORT
+    (bit-identical generator), one song per thread at a time.  TIMED with the baseline-only build (oracle/Makefile
+    `native`: -O3 -march=native, vectorisable radix-4 FFT, compiled on this machine) at two thread counts -- the port is
+    memory-bound well before it runs out of cores -- and the better one is reported with the thread count it used; the
+    parity CHECK of the GPU rows uses the default build (the pinned checker), timed too for reference.  This is a PORT
     (kind: "port"), not bliss-rs itself: see DESIGN.md section 5 for what that does and does not say."""
     O = oracle_mod()
     ncpu = os.cpu_count() or 1
@@ -84,20 +86,33 @@ def cpu_baseline(global_indices, lengths, features_version=2):
     lens = np.asarray(lengths, np.uint64)
     offs = np.zeros(n, np.uint64)
     offs[1:] = np.cumsum(lens)[:-1]
-    tried, out = [], None
-    for cores in sorted({min(ncpu, n, 32), min(ncpu, n, 64)}):
-        t0 = time.perf_counter()
-        out, status = O.song_analyze_batch(pcm, offs, lens, features_version, cores)
-        tried.append((n / (time.perf_counter() - t0), cores))
+    t0 = time.perf_counter()
+    out, status = O.song_analyze_batch(pcm, offs, lens, features_version, min(ncpu, n, 32))
+    checker_rate = n / (time.perf_counter() - t0)
+    tried, fast_note = [], "baseline-only build (-O3 -march=native, radix-4 FFT)"
+    try:
+        for cores in sorted({min(ncpu, n, 32), min(ncpu, n, 64)}):
+            t0 = time.perf_counter()
+            fast, _ = O.song_analyze_batch(pcm, offs, lens, features_version, cores, fast=True)
+            tried.append((n / (time.perf_counter() - t0), cores))
+        fast_dev = float(np.abs(fast - out).max())
+    except Exception as e:  # noqa: BLE001  (no compiler on the box: fall back to the checker's own timing, say so)
+        tried, fast_note, fast_dev = [(checker_rate, min(ncpu, n, 32))], f"default build only ({type(e).__name__})", None
     rate, cores = max(tried)
     res = {"value": round(rate, 3), "unit": "songs/sec", "cores": cores, "kind": "port",
-           "sample": f"{n} of the same white-noise songs ({int(lens.sum())} samples), oracle/bliss_oracle.c (a port, not "
-                     "bliss-rs: its FFT is a plain radix-2, rustfft is SIMD mixed-radix); "
-                     + ", ".join(f"{c} threads: {r:.1f} songs/s" for r, c in tried) + f" ({ncpu} logical CPUs)",
-           "samples_per_sec": round(rate * float(lens.mean()), 1)}
+           "sample": f"{n} of the same white-noise songs ({int(lens.sum())} samples), oracle/bliss_oracle.c, {fast_note} -- an "
+                     "oracle port, not bliss-rs (rustfft is SIMD mixed-radix); "
+                     + ", ".join(f"{c} threads: {r:.1f} songs/s" for r, c in tried) + f" ({ncpu} logical CPUs); "
+                     f"default (checker) build: {checker_rate:.1f} songs/s",
+           "samples_per_sec": round(rate * float(lens.mean()), 1),
+           "max_abs_dev_baseline_build_vs_checker": fast_dev}
     try:  # per-descriptor seconds of ONE song on one core: where the CPU time goes
         k = int(np.argmin(np.abs(lens.astype(np.int64) - int(np.median(lens)))))
-        res["per_descriptor_seconds_one_song"] = O.song_analyze_timed(pcm[int(offs[k]):int(offs[k] + lens[k])], features_version)
+        one = pcm[int(offs[k]):int(offs[k] + lens[k])]
+        try:
+            res["per_descriptor_seconds_one_song"] = O.song_analyze_timed(one, features_version, fast=True)
+        except Exception:  # noqa: BLE001
+            res["per_descriptor_seconds_one_song"] = O.song_analyze_timed(one, features_version)
     except Exception as e:  # noqa: BLE001
         res["per_descriptor_seconds_one_song"] = {"error": str(e)[:200]}
     return res, out
