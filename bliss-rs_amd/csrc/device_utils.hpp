@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace bg {
 
 constexpr int WAVE = 64;
@@ -48,6 +50,35 @@ __device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v) {
         if (l >= off) v += o;
     }
     return v;
+}
+
+// the same scan with DPP only (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31 across them):
+// six VALU instructions, no trip through the LDS crossbar and its latency (ds_bpermute)
+__device__ __forceinline__ uint32_t wave_scan_incl_u32_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1, zero fill
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// wave-wide maximum with DPP row operations + four v_readlane (no ds_bpermute: its LDS-crossbar latency would be paid six
+// times in a row); every lane gets the result
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0xB1>{}));    // quad_perm xor 1
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x4E>{}));    // quad_perm xor 2
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x141>{}));   // row_half_mirror
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x140>{}));   // row_mirror: every lane of a row holds the row maximum
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // ---- complex helpers ----

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         }
         const bool has_next = fi + 1 < STFT_FRAMES_PER_WG && f + 1 < sd.n_c;  // uniform
         if (has_next) load_frame(f + 1, v);
-        mx = wave_max(mx);
+        mx = wave_max_dpp(mx);
         // The split only reads the UPPER half of the exchange buffer (complex slots 2049..4095 = bytes 16 392..32 767);
         // the row of 4112 magnitudes goes into the dead lower half (words 0..4095) and, for bin 4096 and the zero padding,
         // into the 2 KB behind the upper half -- no barrier between the split reads and these writes.
@@ -472,19 +472,31 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         const double ref = 0.1 * (double)mx;
         const float thr = ref_floor_f32(ref);
         {
+            // nine magnitudes at a time (one wait for the LDS instead of three), then branch-free tests
             uint32_t hits = 0;  // bit j: bin t + 256 j is a peak
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                const int c = t + 256 * j;
-                const float sb = mags[c > 0 ? c - 1 : 0], se = mags[c], sa = mags[c + 1];
-                const bool pk = c >= PIP_LO && c <= PIP_HI && sa <= se && sb < se && se > thr;
-                hits |= (pk ? 1u : 0u) << j;
+            for (int h = 0; h < 2; h++) {
+                float sb3[3], se3[3], sa3[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const int c = t + 256 * (3 * h + q);
+                    sb3[q] = mags[c > 0 ? c - 1 : 0];
+                    se3[q] = mags[c];
+                    sa3[q] = mags[c + 1];
+                }
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const int j = 3 * h + q, c = t + 256 * j;
+                    const uint32_t in_range = (256 * j >= PIP_LO && 256 * j + 255 <= PIP_HI) ? 1u : (uint32_t)(c >= PIP_LO) & (uint32_t)(c <= PIP_HI);
+                    const uint32_t pk = in_range & (uint32_t)(sa3[q] <= se3[q]) & (uint32_t)(sb3[q] < se3[q]) & (uint32_t)(se3[q] > thr);
+                    hits |= pk << j;
+                }
             }
             const uint32_t mine = (uint32_t)__popc(hits);
-            const uint32_t incl = wave_scan_incl_u32(mine);
+            const uint32_t incl = wave_scan_incl_u32_dpp(mine);
             uint32_t wbase = 0;
             if (lane_id() == 63) wbase = atomicAdd(&peak_count, incl);  // the wave's slice of the list
-            uint32_t pos = __shfl(wbase, 63, WAVE) + incl - mine;
+            uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63) + incl - mine;
 #pragma unroll
             for (int j = 0; j < 6; j++)
                 if ((hits >> j) & 1u) peak_list[pos++] = (uint16_t)(t + 256 * j);
@@ -492,9 +504,13 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
             const uint32_t n_peaks = peak_count;
             uint32_t* __restrict__ recs = peak_rec + (sd.c_off + f) * (size_t)PIP_MAX_PER_FRAME;
             if (t == 0) peak_cnt[sd.c_off + f] = n_peaks;
+            // the next list entry is requested together with this peak's magnitudes: the dependent LDS latencies
+            // (list -> magnitudes) overlap across the two or three peaks a thread classifies
+            int c_next = t < n_peaks ? (int)peak_list[t] : PIP_LO;
             for (uint32_t i = t; i < n_peaks; i += 256) {
-                const int c = peak_list[i];
+                const int c = c_next;
                 const float sb = mags[c - 1], se = mags[c], sa = mags[c + 1];
+                c_next = i + 256 < n_peaks ? (int)peak_list[i + 256] : PIP_LO;
                 int pb;
                 const uint32_t b = peak_classify(sb, se, sa, ref, c, &pb), rel = b - lbase;
                 recs[i] = peak_record(b, pb, c);

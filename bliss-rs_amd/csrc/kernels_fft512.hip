@@ -56,6 +56,20 @@ __device__ __forceinline__ T row16_sum(T v) {  // every lane of the row gets the
     v += dpp_mov<DPP_ROW_MIRROR>(v);
     return v;
 }
+// product of a double across the row: the two halves of the value travel by DPP (VALU only -- a ds_bpermute butterfly
+// would pay the LDS crossbar latency four times per frame)
+__device__ __forceinline__ double row16_prod(double v) {
+    auto step = [](double x, auto ctrl) {
+        const long long b = __double_as_longlong(x);
+        const int lo = dpp_mov<decltype(ctrl)::value>((int)(b & 0xFFFFFFFFll)), hi = dpp_mov<decltype(ctrl)::value>((int)(b >> 32));
+        return x * __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    };
+    v = step(v, std::integral_constant<int, DPP_QUAD_XOR1>{});
+    v = step(v, std::integral_constant<int, DPP_QUAD_XOR2>{});
+    v = step(v, std::integral_constant<int, DPP_ROW_HALF_MIRROR>{});
+    v = step(v, std::integral_constant<int, DPP_ROW_MIRROR>{});
+    return v;
+}
 __device__ __forceinline__ float row16_scan_incl(float v) {  // row_shr:n with zero fill
     v += dpp_mov<0x111>(v);
     v += dpp_mov<0x112>(v);
@@ -292,8 +306,7 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
             }
             const int any_zero = row16_sum(zero);
             const int exps = row16_sum(expo);
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) mant *= __shfl_xor(mant, off, 16);
+            mant = row16_prod(mant);
             // The scalar tail (two divisions, log2, exp2, the normalisations: ~40 instructions) would run identically on all
             // 16 lanes of the group; instead lane k mod 16 keeps the reduced sums of frame k and every 16 frames each lane
             // finishes ITS frame -- one pass of the scalar tail serves 16 frames, and the three stores become coalesced.
