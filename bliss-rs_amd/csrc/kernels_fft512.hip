@@ -113,15 +113,23 @@ __device__ __forceinline__ void fft512_load(__amdgpu_buffer_rsrc_t r_x, long rel
     }
 }
 
+// the lane's constants, register resident for the whole kernel (94 VGPRs): the window of its 16 sample pairs, its 15
+// inter-pass twiddles, its 16 split twiddles
+struct RegTables {
+    f2 win[16];    // (hannz[2n], hannz[2n+1]), n = 16 n1 + l
+    f2 tw256[16];  // W_256^(l*k1)
+    f2 tw512[16];  // W_512^(16 l + e)
+};
+
 // 257 magnitudes of one frame: lane l of the group gets bins 16l..16l+15
 template <int R>
-__device__ __forceinline__ void fft512_compute(f2 (&raw)[16], int l, f2* tile, const Tables512* tabs, FrameMags& out) {
+__device__ __forceinline__ void fft512_compute(f2 (&raw)[16], int l, f2* tile, const RegTables& tabs, FrameMags& out) {
     f2 v[16];
 #pragma unroll
-    for (int n1 = 0; n1 < 16; n1++) v[n1] = row<R>(raw, n1) * tabs->win[16 * n1 + l];
+    for (int n1 = 0; n1 < 16; n1++) v[n1] = row<R>(raw, n1) * tabs.win[n1];
     radix16(v);  // over n1 -> A[k1] at v[R16(k1)]
 #pragma unroll
-    for (int k1 = 1; k1 < 16; k1++) v[R16(k1)] = cmul_pk(v[R16(k1)], tabs->tw256[16 * k1 + l]);  // W_256^(l*k1)
+    for (int k1 = 1; k1 < 16; k1++) v[R16(k1)] = cmul_pk(v[R16(k1)], tabs.tw256[k1]);  // W_256^(l*k1)
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) tile[k1 * 17 + l] = v[R16(k1)];
     __builtin_amdgcn_wave_barrier();
@@ -139,7 +147,7 @@ __device__ __forceinline__ void fft512_compute(f2 (&raw)[16], int l, f2* tile, c
         // Z[256 - k], k = 16 l + e  (k = 0 pairs with itself)
         const int mi = (e == 0) ? ((l == 0) ? 0 : 17 * (16 - l)) : (17 * (15 - l) + 16 - e);
         const f2 zm = tile[mi];
-        out.m[e] = mag_from_sq(split_one_sq(zk, zm, tabs->tw512[16 * e + l]));  // W_512^k, k = 16 l + e
+        out.m[e] = mag_from_sq(split_one_sq(zk, zm, tabs.tw512[e]));  // W_512^k, k = 16 l + e
     }
     // Z is halved (half window): X[0] = 2 (Re Z[0] + Im Z[0]), X[256] = 2 (Re Z[0] - Im Z[0])
     if (l == 0) out.m[0] = 2.0f * fabsf(z0.x + z0.y);
@@ -167,7 +175,7 @@ __device__ __forceinline__ void stats128(const f2 r0, const f2 r1, const f2 r2, 
     zc += (uint32_t)(((x0 ^ p0) + (y0 ^ x0)) + ((x1 ^ p1) + (y1 ^ x1)) + ((x2 ^ p2) + (y2 ^ x2)) + ((x3 ^ p3) + (y3 ^ x3)));
 }
 
-__global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict__ pcm,
+__global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict__ pcm,
                                                         const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                         const uint32_t* __restrict__ pfx_f,
                                                         const float* __restrict__ hannz,
@@ -176,16 +184,17 @@ __global__ __launch_bounds__(256, 3) void fft512_kernel(const float* __restrict_
                                                         float* __restrict__ flatness, float* __restrict__ flux,
                                                         float* __restrict__ e256, uint32_t* __restrict__ zc256) {
     __shared__ f2 lds[GROUPS_PER_WG * GRP_PITCH];
-    __shared__ Tables512 tabs_s;
+    RegTables tabs;
     {
-        const int t = threadIdx.x;  // t = 16 a + b
-        const float2 a = tw512[2 * (((t >> 4) * (t & 15)) & 255)], b = tw512[16 * (t & 15) + (t >> 4)];
-        tabs_s.win[t] = mk(hannz[2 * t], hannz[2 * t + 1]);
-        tabs_s.tw256[t] = mk(a.x, a.y);  // W_256^(k1*l) = W_512^(2 k1 l)
-        tabs_s.tw512[t] = mk(b.x, b.y);
+        const int l0 = threadIdx.x & 15;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float2 a = tw512[2 * ((i * l0) & 255)], b = tw512[16 * l0 + i];
+            tabs.win[i] = mk(hannz[2 * (16 * i + l0)], hannz[2 * (16 * i + l0) + 1]);
+            tabs.tw256[i] = mk(a.x, a.y);  // W_256^(k1*l) = W_512^(2 k1 l)
+            tabs.tw512[i] = mk(b.x, b.y);
+        }
     }
-    __syncthreads();
-    const Tables512* tabs = &tabs_s;
     const uint32_t s = find_segment(pfx_f, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
     const uint32_t tile_idx = blockIdx.x - pfx_f[s];
