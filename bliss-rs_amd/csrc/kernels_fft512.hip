@@ -160,19 +160,33 @@ __device__ __forceinline__ void fft512_compute(f2 (&raw)[16], int l, f2* tile, c
 // src/aubio.rs:1258-1276) and the zero-crossing count (number_crossings, src/utils.rs:81-95: a crossing is a change of
 // `x > 0` between consecutive samples; the first sample of the song compares with itself).  FFT frame k brings in the
 // 128 samples [128 k, 128 k + 128) = rows 12..15 of its window; `before` is row 11, whose last sample precedes them. ----
-constexpr int DPP_ROW_ROR1 = 0x121;
+// acc += bit `lane` of mask: one VALU instruction (the 64-bit lane mask is the carry-in of an add-with-carry)
+__device__ __forceinline__ void add_lane_bit(uint32_t& acc, uint64_t mask) {
+    asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(acc) : "s"(mask) : "vcc");
+}
+
+// The sign tests produce 64-bit lane masks (v_cmp writes an SGPR pair); comparing a sample with its predecessor is then
+// SCALAR bit arithmetic on those masks -- the idle scalar unit instead of the busy vector one: within a row the samples
+// run x(lane 0), y(lane 0), x(lane 1), ..., so "y against its x" is Mx ^ My and "x against the y before it" is
+// Mx ^ (My << 1) with bit 0 of every 16-lane group replaced by lane 15 of the row before (or, at the very first sample
+// of the song, by the sample itself: no crossing).  A lane then adds its own bit of each mask.
 __device__ __forceinline__ void stats128(const f2 r0, const f2 r1, const f2 r2, const f2 r3, const f2 before, bool song_start,
-                                         int l, float& ss, uint32_t& zc) {
+                                         float& ss, uint32_t& zc) {
     ss += ((r0.x * r0.x + r0.y * r0.y) + (r1.x * r1.x + r1.y * r1.y)) + ((r2.x * r2.x + r2.y * r2.y) + (r3.x * r3.x + r3.y * r3.y));
-    const int x0 = r0.x > 0.0f, y0 = r0.y > 0.0f, x1 = r1.x > 0.0f, y1 = r1.y > 0.0f;
-    const int x2 = r2.x > 0.0f, y2 = r2.y > 0.0f, x3 = r3.x > 0.0f, y3 = r3.y > 0.0f;
-    const int yb = before.y > 0.0f;
-    // the sample before a lane's .x: the previous lane's .y of the same row; lane 0 takes lane 15 of the row before
-    const int a0 = dpp_mov<DPP_ROW_ROR1>(y0), a1 = dpp_mov<DPP_ROW_ROR1>(y1), a2 = dpp_mov<DPP_ROW_ROR1>(y2);
-    const int a3 = dpp_mov<DPP_ROW_ROR1>(y3), ab = dpp_mov<DPP_ROW_ROR1>(yb);
-    const bool first = l == 0;
-    const int p0 = first ? (song_start ? x0 : ab) : a0, p1 = first ? a0 : a1, p2 = first ? a1 : a2, p3 = first ? a2 : a3;
-    zc += (uint32_t)(((x0 ^ p0) + (y0 ^ x0)) + ((x1 ^ p1) + (y1 ^ x1)) + ((x2 ^ p2) + (y2 ^ x2)) + ((x3 ^ p3) + (y3 ^ x3)));
+    constexpr uint64_t LOW = 0x0001000100010001ull;  // lane 0 of the four 16-lane groups
+    const uint64_t x0 = __ballot(r0.x > 0.0f), y0 = __ballot(r0.y > 0.0f), x1 = __ballot(r1.x > 0.0f), y1 = __ballot(r1.y > 0.0f);
+    const uint64_t x2 = __ballot(r2.x > 0.0f), y2 = __ballot(r2.y > 0.0f), x3 = __ballot(r3.x > 0.0f), y3 = __ballot(r3.y > 0.0f);
+    const uint64_t yb = __ballot(before.y > 0.0f), start = __ballot(song_start);
+    auto shifted = [&](uint64_t y, uint64_t prev_bits) { return ((y << 1) & ~LOW) | prev_bits; };
+    const uint64_t p0 = (((yb >> 15) & ~start) | (x0 & start)) & LOW;
+    add_lane_bit(zc, x0 ^ y0);
+    add_lane_bit(zc, x0 ^ shifted(y0, p0));
+    add_lane_bit(zc, x1 ^ y1);
+    add_lane_bit(zc, x1 ^ shifted(y1, (y0 >> 15) & LOW));
+    add_lane_bit(zc, x2 ^ y2);
+    add_lane_bit(zc, x2 ^ shifted(y2, (y1 >> 15) & LOW));
+    add_lane_bit(zc, x3 ^ y3);
+    add_lane_bit(zc, x3 ^ shifted(y3, (y2 >> 15) & LOW));
 }
 
 __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict__ pcm,
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
     auto frame = [&](auto jc, long k, FrameMags& cur, FrameMags& prev) {
         constexpr int J = decltype(jc)::value;
         constexpr int R = (4 * J) & 15;
-        stats128(row<R>(raw, 12), row<R>(raw, 13), row<R>(raw, 14), row<R>(raw, 15), row<R>(raw, 11), k == 0, l, ss_acc, zc_acc);
+        stats128(row<R>(raw, 12), row<R>(raw, 13), row<R>(raw, 14), row<R>(raw, 15), row<R>(raw, 11), k == 0, ss_acc, zc_acc);
         __builtin_amdgcn_sched_barrier(0);
         fft512_compute<R>(raw, l, tile, tabs, cur);
         if (k + 1 < k_end) {
