@@ -681,30 +681,49 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
         __builtin_amdgcn_wave_barrier();
         n_slow = 0;
     };
+    // A frame has up to 714 records = 12 words per lane; they are requested four at a time (and the next frame's record
+    // count one frame ahead), so a frame pays the memory latency three times at most instead of once per 64 records.
+    uint32_t n_rec_next = 0;
+    {
+        const uint32_t f0 = tile * CH_TILE + wave;
+        if (f0 < sd.n_c) n_rec_next = peak_cnt[sd.c_off + f0];
+    }
     for (int i = 0; i < P2_FRAMES_PER_WAVE; i++) {
         const uint32_t f = tile * CH_TILE + wave + 4 * i;
         if (f >= sd.n_c) break;  // wave-uniform
-        const uint32_t n_rec = peak_cnt[sd.c_off + f];
+        const uint32_t n_rec = n_rec_next;
+        if (i + 1 < P2_FRAMES_PER_WAVE && f + 4 < sd.n_c) n_rec_next = peak_cnt[sd.c_off + f + 4];
         const uint32_t* __restrict__ recs = peak_rec + (sd.c_off + f) * (size_t)PIP_MAX_PER_FRAME;
         if (n_slow + PIP_MAX_PER_FRAME > P2_SLOW_CAP) flush();  // wave-uniform
-        for (uint32_t j = lane; j < ((n_rec + WAVE - 1) / WAVE) * WAVE; j += WAVE) {  // uniform trip count
-            bool slow = false;
-            uint32_t c = 0;
-            if (j < n_rec) {
-                const uint32_t r = recs[j];
-                const uint32_t b = r >> 18, pbf = (r >> 11) & 0x7Fu;
-                c = r & 0x7FFu;
-                if (b > b_hi) {
-                    if (pbf) atomicAdd(&hist[pbf - 1], 1u);
-                    else slow = true;
-                } else if (b >= b_lo) {
-                    slow = true;
-                }
+        for (uint32_t j0 = 0; j0 < n_rec; j0 += 4 * WAVE) {  // uniform trip count
+            uint32_t r4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = j0 + WAVE * u + lane;
+                r4[u] = j < n_rec ? recs[j] : 0xFFFFFFFFu;
             }
-            const uint64_t mask = __ballot(slow);
-            if (mask) {
-                if (slow) slow_list[wave][n_slow + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = ((uint32_t)i << 16) | c;
-                n_slow += (uint32_t)__popcll(mask);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (j0 + WAVE * u >= n_rec) break;  // wave-uniform
+                const uint32_t j = j0 + WAVE * u + lane;
+                bool slow = false;
+                uint32_t c = 0;
+                if (j < n_rec) {
+                    const uint32_t r = r4[u];
+                    const uint32_t b = r >> 18, pbf = (r >> 11) & 0x7Fu;
+                    c = r & 0x7FFu;
+                    if (b > b_hi) {
+                        if (pbf) atomicAdd(&hist[pbf - 1], 1u);
+                        else slow = true;
+                    } else if (b >= b_lo) {
+                        slow = true;
+                    }
+                }
+                const uint64_t mask = __ballot(slow);
+                if (mask) {
+                    if (slow) slow_list[wave][n_slow + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = ((uint32_t)i << 16) | c;
+                    n_slow += (uint32_t)__popcll(mask);
+                }
             }
         }
     }
