@@ -9,7 +9,10 @@
 // Per frame this kernel produces
 //   * spectral centroid / rolloff / flatness on the reference's "buggy" 256-bin vector whose bin 255
 //     is |Re X[256]| (src/aubio.rs:240-261, 16-58; src/timbral.rs:154-209; src/utils.rs:101-117)
-//   * for odd frames, the SpecFlux onset value over the correct 257 bins (src/aubio.rs:455-467).
+//   * for odd frames, the SpecFlux onset value over the correct 257 bins (src/aubio.rs:455-467)
+//   * per 256-sample block the sum of squares and the zero-crossing count of the PCM itself (LoudnessDesc,
+//     src/misc.rs:12-18; the tempo silence test, src/aubio.rs:1258-1276; number_crossings, src/utils.rs:81-95):
+//     the kernel already holds every sample in registers, so there is no separate pass over the PCM.
 //
 // Mapping: a 16-lane group owns one frame at a time (4 frames per wavefront, 16 per workgroup).  The
 // 512 real samples are packed as 256 complex values = 16 x 16: each lane holds 16 of them in registers,
@@ -17,7 +20,9 @@
 // pass, and a second LDS round trip re-orders the spectrum so that lane l ends up with the 16
 // CONSECUTIVE bins 16l..16l+15 (needed by the rolloff prefix sum) and with Z[256-k] for the real-input
 // split.  Reductions stay inside the 16-lane row (DPP).  A group walks FRAMES_PER_GROUP consecutive
-// frames so the previous tempo frame's magnitudes stay in registers (one halo FFT per group).
+// frames so the previous tempo frame's magnitudes stay in registers (one halo FFT per group).  The lane's
+// constants (window, twiddles) are register resident: two waves per SIMD without table reads beat three
+// waves with LDS tables.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -81,13 +86,6 @@ __device__ __forceinline__ float row16_scan_incl(float v) {  // row_shr:n with z
 struct FrameMags {
     float m[16];  // |X[16l + e]|
     float nyq;    // |X[256]| (every lane)
-};
-
-// constant tables staged once per workgroup in LDS (broadcast reads, no VMEM traffic per frame)
-struct Tables512 {
-    f2 win[256];    // (hannz[2n], hannz[2n+1]), n = 16 n1 + l
-    f2 tw256[256];  // W_256^(l*k1) at [16 k1 + l]
-    f2 tw512[256];  // W_512^(16 l + e) at [16 e + l]: lane-contiguous (a [16 l + e] layout is a 16-way bank conflict)
 };
 
 // Raw sample rows of a lane group live in a ROTATING register window: row n1 of the frame with rotation R (= 4 x its
