@@ -173,6 +173,29 @@ def test_python_threads_coalesce_and_stay_bit_identical(bliss, oracle):
         assert np.array_equal(batch[i].as_arr1(), serial[i])
 
 
+def test_coalesced_batch_with_mixed_input_classes(bliss, oracle):
+    """threads handing over different decoder outputs at once (mono f32, stereo s16, version 1 rows): the front runs one
+    device batch per class and every caller still gets its own row, bit-identical to the serial call"""
+    stereo = load_golden("s16_stereo_22_5kHz.pcm_s16.npy")[:120000]
+    mono = oracle.white_noise(950, 9 * 22050)
+    v1 = bliss.AnalysisOptions(bliss.FeaturesVersion.Version1)
+    jobs = [(mono, None), (stereo, None), (mono, v1), (stereo, v1)] * 3
+    want = [bliss.Song.analyze_with_options(x, o or bliss.AnalysisOptions()).as_arr1() for x, o in jobs[:4]]
+    got = [None] * len(jobs)
+
+    def worker(i):
+        x, o = jobs[i]
+        got[i] = bliss.Song.analyze_with_options(x, o or bliss.AnalysisOptions()).as_arr1()
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for i in range(len(jobs)):
+        assert got[i].shape == want[i % 4].shape and np.array_equal(got[i], want[i % 4])
+
+
 def test_two_contexts_run_concurrently_from_two_threads(bliss, oracle):
     songs = [oracle.white_noise(700 + i, 6 * 22050 + 1000 * i) for i in range(6)]
     ref, _ = _run(bliss.Context(0), songs)
