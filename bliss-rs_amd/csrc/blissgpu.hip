@@ -153,8 +153,12 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
     // instead of queueing behind the thousands of workgroups of an FFT kernel
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (const char* e = getenv("BLISSGPU_SIDE_PRIORITY")) { if (atoi(e) == 0) prio_greatest = prio_least; }  // developer aid
-    se = hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio_greatest);
+    int prio_aux = prio_greatest;
+    if (const char* e = getenv("BLISSGPU_SIDE_PRIORITY")) {  // developer aid: 0 = both normal, 2 = only the tuning stream high
+        if (atoi(e) == 0) prio_greatest = prio_aux = prio_least;
+        if (atoi(e) == 2) prio_aux = prio_least;
+    }
+    se = hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio_aux);
     if (se == hipSuccess) se = hipStreamCreateWithPriority(&c->chr_stream, hipStreamNonBlocking, prio_greatest);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_interop, hipEventDisableTiming);
     if (se == hipSuccess) se = hipHostMalloc((void**)&c->h_scalar, 64, hipHostMallocDefault);

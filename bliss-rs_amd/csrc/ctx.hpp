@@ -77,7 +77,7 @@ struct ChunkSlot {
     DevBuf<uint8_t> slab;        // workspace carved per chunk
     DevBuf<uint8_t> desc;        // SongDesc[] + tile prefix arrays
     PinnedBuf<uint8_t> h_desc;   // pinned staging of desc
-    hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_stft = nullptr, ev_tune = nullptr, ev_sum = nullptr, ev_chroma = nullptr;
+    hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_stft = nullptr, ev_sel = nullptr, ev_tune = nullptr, ev_sum = nullptr, ev_chroma = nullptr;
     hipEvent_t ev_desc = nullptr;  // recorded on the main stream after the descriptor copy: the staging area is free
     hipEvent_t ev_free = nullptr;  // recorded on the aux stream after the row assembly: the slot is free
     bool used = false;

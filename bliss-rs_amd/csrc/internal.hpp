@@ -28,6 +28,7 @@ constexpr int PIP_MAX_PER_FRAME = 714;    // peaks cannot be adjacent: ceil(1427
 constexpr int CAND_BUDGET_PER_FRAME = 48; // tuning-candidate pool of a chunk: slots per chroma frame (white noise needs ~8; see tune_select_kernel)
 constexpr int H1_BINS = 8192;             // coarse magnitude histogram: f32 bit pattern >> 18
 constexpr int BT_WINLEN = 512, BT_STEP = 128, BT_LAGLEN = 128;  // src/aubio.rs:1337-1341, 920-922
+constexpr int BT_PRE_STRIDE = 264;  // floats per beat-tracker run written by beat_acf_kernel (kernels_tempo.hip)
 constexpr int F512_TILE = 512;            // FFT-512 frames per workgroup (16 lane-groups x 32 consecutive frames + 1 halo frame each)
 constexpr int CH_TILE = 64;               // chroma frames per workgroup in the contraction kernel
 constexpr int STFT_TILE = 16;             // chroma frames per workgroup in the STFT kernel
@@ -129,6 +130,7 @@ struct Workspace {
     float* run_bpm;         // [n_songs][runs_pitch] bpm after each beat-tracker run
     uint32_t* run_cnt;      // [n_songs][runs_pitch] beats recorded while that bpm was current
     uint32_t runs_pitch;
+    float* bt_pre;          // [total_b / 128 + n_songs][BT_PRE_STRIDE] per-run records; song s starts at run b_off / 128 + s
     float* summary;         // [n_songs][16] features 1..9 (zcr, timbral, loudness summaries)
 };
 

@@ -3,10 +3,16 @@
 //
 //   onset_kernel : PeakPicker threshold (src/aubio.rs:733-768, 661-685, 482-554): a pure function of
 //                  the last 7 SpecFlux values, so one thread per tempo frame.
-//   beat_kernel  : Tempo::do_ (src/aubio.rs:1378-1443) + BeatTracking::{do_, checkstate, get_timesig,
-//                  get_bpm} (:966-1240) + BPMDesc (src/temporal.rs:50-77).  The beat tracker is the one
-//                  sequential chain on the path (state gp/rp1/rp2/counter/flagstep/timesig/lastbeat/
-//                  gwv/phwv), so one workgroup per song walks its ~121 runs while songs run in parallel.
+//   beat_acf_kernel   : the state-independent half of BeatTracking::do_ (src/aubio.rs:966-1003): the
+//                  autocorrelation of every run's detection-function frame, its comb filterbank sums
+//                  for both time signatures, the Rayleigh-weighted period and get_timesig (:864-907)
+//                  -- one workgroup per (song, run), ~124 k of them for 1024 three-minute songs.
+//   beat_track_kernel : the sequential half: checkstate (:1096-1227), beat phase (:1025-1054),
+//                  Tempo::do_'s beat / silence test (:1378-1443), get_bpm and BPMDesc's median
+//                  (src/temporal.rs:50-77).  The chain (gp/rp1/rp2/counter/flagstep/timesig/lastbeat/
+//                  gwv/phwv) is walked by ONE wavefront per song with no workgroup barrier: its inputs are
+//                  prefetched a run ahead, so a run costs a few microseconds and the kernel holds 1/16 of
+//                  the registers the former one-workgroup-per-song tracker did.
 #include "device_utils.hpp"
 #include "internal.hpp"
 
@@ -80,33 +86,26 @@ void launch_onset(const Batch& b, const Workspace& w, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// vec_max_elem (src/aubio.rs:787-799): last index attaining the maximum, scanning with tmp = 0
-// (so a vector with no element >= 0 yields index 0).  Block-wide; result broadcast through LDS.
-__device__ __forceinline__ int block_argmax_last(const float* v, int n, float* s_val, int* s_idx) {
-    const int tid = threadIdx.x;
+// vec_max_elem (src/aubio.rs:787-799): last index attaining the maximum, scanning with tmp = 0 (so a
+// vector with no element >= 0 yields index 0).  One wavefront; element i = lane + 64 q is x[q].
+// Returns (value, index) with value = -1 when no element is >= 0.
+template <int Q>
+__device__ __forceinline__ void wave_argmax_last(const float (&x)[Q], float* val, int* idx) {
+    const int lane = lane_id();
     float best = -1.0f;  // "no candidate" marker: candidates are >= 0
     int bidx = 0;
-    for (int i = tid; i < n; i += 256) {
-        const float x = v[i];
-        if (x >= 0.0f && x >= best) { best = x; bidx = i; }  // i increases: keeps the last among equals
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        if (x[q] >= 0.0f && x[q] >= best) { best = x[q]; bidx = lane + 64 * q; }  // index increases: keeps the last among equals
     }
-    // wave reduce (value, then larger index)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float ov = __shfl_xor(best, off, WAVE);
         const int oi = __shfl_xor(bidx, off, WAVE);
         if (ov > best || (ov == best && oi > bidx)) { best = ov; bidx = oi; }
     }
-    __syncthreads();
-    if (lane_id() == 0) { s_val[wave_id()] = best; s_idx[wave_id()] = bidx; }
-    __syncthreads();
-    float b = s_val[0];
-    int bi = s_idx[0];
-#pragma unroll
-    for (int w = 1; w < 4; w++) {
-        if (s_val[w] > b || (s_val[w] == b && s_idx[w] > bi)) { b = s_val[w]; bi = s_idx[w]; }
-    }
-    return (b < 0.0f) ? 0 : bi;
+    *val = best;
+    *idx = (best < 0.0f) ? 0 : bidx;
 }
 
 // vec_quadratic_peak_pos (src/aubio.rs:576-604)
@@ -135,214 +134,290 @@ __device__ float bt_timesig(const float* acf, long gp) {
     return three > four ? 3 : 4;
 }
 
+// Per-run record written by beat_acf_kernel: everything BeatTracking::do_ derives from the run's frame alone.
+//   [0, 128)   g3: unweighted comb sums for time signature 3 (the gwv path of checkstate, :1110-1124)
+//   [128, 256) g4: the same for time signature 4
+//   [256] rp3  [257] rp4 : Rayleigh-weighted period with numelem 3 / 4 (:987-1013)
+//   [258] ts3  [259] ts4 : get_timesig(acf, rp3 / rp4), what checkstate would set when it locks onto that period
+constexpr int BT_PRE_G3 = 0, BT_PRE_G4 = BT_LAGLEN, BT_PRE_RP3 = 256, BT_PRE_RP4 = 257, BT_PRE_TS3 = 258, BT_PRE_TS4 = 259;
+static_assert(BT_PRE_STRIDE >= 260, "per-run record");
+
+typedef float bt_f2 __attribute__((ext_vector_type(2)));
+
+// acc += f[i] * (w[i], w[i + 1]) for 16 consecutive i: the lag pair (L, L + 1) of one thread, w = frame + L.  w1 is the
+// same series one element on (a second copy in LDS), so that the odd steps' operand pairs (w[i], w[i + 1]) also arrive in
+// even-aligned register pairs: gfx950 takes 64-bit operands from aligned pairs only, and a copy per step costs more than
+// the LDS read.
+template <typename F>
+__device__ __forceinline__ void acf_block16(bt_f2& acc, const float* w, const float* w1, F&& f_at) {
+    float r[16], r1[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { r[u] = w[u]; r1[u] = w1[u]; }
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) {
+        const float f0 = f_at(u), f1 = f_at(u + 1);
+        const bt_f2 w_even = {r[u], r[u + 1]}, w_odd = {r1[u], r1[u + 1]};
+        const bt_f2 fv0 = {f0, f0}, fv1 = {f1, f1};
+        acc = acc + fv0 * w_even;
+        acc = acc + fv1 * w_odd;
+    }
+}
+
+__global__ __launch_bounds__(128) void beat_acf_kernel(const SongDesc* __restrict__ songs,
+                                                       const float* __restrict__ thresholded,
+                                                       const float* __restrict__ rwv_tab,
+                                                       float* __restrict__ pre_all) {
+    __shared__ float df[2 * BT_WINLEN];  // [512, 1024) stays zero: the ACF loops read past the frame instead of predicating
+    __shared__ float df1[2 * BT_WINLEN];  // df1[j] = df[j + 1]
+    __shared__ float acf[BT_WINLEN];
+    __shared__ float acfout[2][BT_LAGLEN];
+    const uint32_t s = blockIdx.y;
+    const long m = blockIdx.x;
+    const SongDesc sd = songs[s];
+    if (!sd.ok) return;
+    const long n_b = sd.n_b;
+    const long n_runs = (n_b >= BT_STEP) ? (n_b - BT_STEP) / BT_STEP + 1 : 0;
+    if (m >= n_runs) return;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const float* thr = thresholded + sd.b_off;
+    float* pre = pre_all + ((size_t)(sd.b_off / BT_STEP) + s + (size_t)m) * BT_PRE_STRIDE;
+
+    // ---- dfframe for run m: s[128(m+1)-512+i], s[x] = 0 for x <= 0, thr[x-1] otherwise (Tempo::do_ :1389-1416) ----
+    {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {  // all four loads in flight together; the address is clamped instead of branching
+            const long xi = 128 * (m + 1) - 512 + tid + 128 * q;
+            const float x = thr[xi > 0 ? xi - 1 : 0];
+            v[q] = (xi <= 0) ? 0.0f : x;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = tid + 128 * q;
+            df[i] = v[q];
+            if (i > 0) df1[i - 1] = v[q];
+            df[BT_WINLEN + i] = 0.0f;
+            df1[BT_WINLEN - 1 + i] = 0.0f;
+        }
+    }
+    __syncthreads();
+    // vec_autocorr (:819-828): acf[L] = (sum_{j=L}^{511} f[j-L] f[j]) / (512 - L), summed in j order.  A thread owns
+    // the lag pairs (2t, 2t+1) and (510-2t, 511-2t) -- a long and a short pair, so both wavefronts do the same work --
+    // and runs i = j - L over the two lags of a pair at once (packed multiply, packed add).  The first factor f[i] is
+    // wave-uniform, so for runs whose frame lies inside the song it comes from SCALAR loads of the thresholded series:
+    // the kernel is bound by LDS bandwidth (two dwords per lane and step for the pair), and a broadcast LDS read of
+    // f[i] would add half as much again (measured: 1.69 vs 1.46 ms per 1024 songs).  The loops run to the wave-uniform bound 512 - (smallest lag of the wave) and read the zero padding
+    // behind the frame instead of predicating (x + f * 0 == x exactly, so every sum is bit-identical to the
+    // reference's).
+    {
+        const int la = 2 * tid, lb = BT_WINLEN - 2 - 2 * tid;
+        const int na = BT_WINLEN - 128 * wave, nb = 128 + 128 * wave;
+        bt_f2 acc_a = {0.0f, 0.0f}, acc_b = {0.0f, 0.0f};
+        if (m >= 4) {
+            const float* __restrict__ fs = thr + (128 * (m + 1) - 512) - 1;  // fs[i] == dfframe[i], wave-uniform
+            for (int i = 0; i < na; i += 16) {
+                float sv[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) sv[u] = fs[i + u];
+                acf_block16(acc_a, df + la + i, df1 + la + i, [&](int u) { return sv[u]; });
+            }
+            for (int i = 0; i < nb; i += 16) {
+                float sv[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) sv[u] = fs[i + u];
+                acf_block16(acc_b, df + lb + i, df1 + lb + i, [&](int u) { return sv[u]; });
+            }
+        } else {
+            for (int i = 0; i < na; i += 16) acf_block16(acc_a, df + la + i, df1 + la + i, [&](int u) { return df[i + u]; });
+            for (int i = 0; i < nb; i += 16) acf_block16(acc_b, df + lb + i, df1 + lb + i, [&](int u) { return df[i + u]; });
+        }
+        acf[la] = acc_a.x / (float)(BT_WINLEN - la);
+        acf[la + 1] = acc_a.y / (float)(BT_WINLEN - la - 1);
+        acf[lb] = acc_b.x / (float)(BT_WINLEN - lb);
+        acf[lb + 1] = acc_b.y / (float)(BT_WINLEN - lb - 1);
+    }
+    __syncthreads();
+    // shift-invariant comb filterbank (:987-1003): the sums run a = 1 .. numelem in order, so the numelem = 4 value is
+    // the numelem = 3 value continued.  Rayleigh path: terms divided by 2a - 1, weighted by rwv; the unweighted sums
+    // are what checkstate weights by its Gaussian (:1110-1124).
+    {
+        const int l = tid;
+        float v3 = 0.0f, v4 = 0.0f, g3 = 0.0f, g4 = 0.0f;
+        if (l >= 1 && l < BT_LAGLEN - 1) {
+            float v = 0.0f, g = 0.0f;
+            for (int a = 1; a <= 4; a++) {
+                if (a == 4) { v3 = v; g3 = g; }
+                for (int b = 1; b < 2 * a; b++) {
+                    const int idx = l * a + b - 1;
+                    if (idx < BT_WINLEN) {
+                        v += acf[idx] / (2.0f * (float)a - 1.0f);
+                        g += acf[idx];
+                    }
+                }
+            }
+            v4 = v; g4 = g;
+        }
+        const float r = rwv_tab[l];
+        acfout[0][l] = v3 * r;
+        acfout[1][l] = v4 * r;
+        pre[BT_PRE_G3 + l] = g3;
+        pre[BT_PRE_G4 + l] = g4;
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63;
+        const float x[2] = {acfout[wave][lane], acfout[wave][lane + 64]};
+        float best;
+        int maxindex;
+        wave_argmax_last(x, &best, &maxindex);
+        if (lane == 0) {
+            const int rayparam = 43;  // (60*22050/120/256) as u32
+            const float rp = (maxindex > 0 && maxindex < BT_LAGLEN - 1) ? quad_peak_pos(acfout[wave], BT_LAGLEN, maxindex)
+                                                                       : (float)rayparam;
+            pre[BT_PRE_RP3 + wave] = rp;
+            pre[BT_PRE_TS3 + wave] = bt_timesig(acf, (long)rp);
+        }
+    }
+}
+
 struct BtShared {
-    float dfframe[2 * BT_WINLEN];  // [512, 1024) stays zero: the ACF loops below read past the frame instead of predicating
-    float dfrev[BT_WINLEN], acf[BT_WINLEN], phout[BT_WINLEN], dfwv[BT_WINLEN];
-    float acfout[BT_LAGLEN], rwv[BT_LAGLEN], gwv[BT_LAGLEN], out[BT_STEP];
-    float phwv[2 * BT_LAGLEN];
-    float red_val[4];
-    int red_idx[4];
-    // scalar state (written by thread 0, read by all after a barrier)
-    float rp, gp, bp, rp1, rp2, lastbeat;
-    int counter, flagstep, timesig, flagconst, phw_mode;
-    uint32_t hit_count;
+    float dfrev[BT_WINLEN];
+    float acfout[BT_LAGLEN];
+    float phout[BT_LAGLEN + 1];  // [128] stays zero: phout is zero from the beat period on (bp < 128)
+    float out[BT_STEP];
 };
 
-
-__global__ __launch_bounds__(256) void beat_kernel(const SongDesc* __restrict__ songs,
-                                                   const float* __restrict__ thresholded,
-                                                   const float* __restrict__ e256,
-                                                   const float* __restrict__ rwv_tab,
-                                                   const float* __restrict__ dfwv_tab,
-                                                   float* __restrict__ run_bpm, uint32_t* __restrict__ run_cnt,
-                                                   uint32_t runs_pitch, TempoState* __restrict__ tempo_out) {
+__global__ __launch_bounds__(64) void beat_track_kernel(const SongDesc* __restrict__ songs,
+                                                        const float* __restrict__ thresholded,
+                                                        const float* __restrict__ e256,
+                                                        const float* __restrict__ dfwv_tab,
+                                                        const float* __restrict__ pre_all,
+                                                        float* __restrict__ run_bpm, uint32_t* __restrict__ run_cnt,
+                                                        uint32_t runs_pitch, TempoState* __restrict__ tempo_out) {
     __shared__ BtShared sh;
     const uint32_t s = blockIdx.x;
     const SongDesc sd = songs[s];
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     if (!sd.ok) {
-        if (tid == 0) { tempo_out[s].tempo = -1.0f; tempo_out[s].n_bpms = 0; }
+        if (lane == 0) { tempo_out[s].tempo = -1.0f; tempo_out[s].n_bpms = 0; }
         return;
     }
     const float* thr = thresholded + sd.b_off;
     const float* en = e256 + sd.e_off;
+    const float* pre_song = pre_all + ((size_t)(sd.b_off / BT_STEP) + s) * BT_PRE_STRIDE;
     float* rbpm = run_bpm + (size_t)s * runs_pitch;
     uint32_t* rcnt = run_cnt + (size_t)s * runs_pitch;
 
-    for (int i = tid; i < BT_WINLEN; i += 256) { sh.dfwv[i] = dfwv_tab[i]; sh.dfframe[BT_WINLEN + i] = 0.0f; }
-    for (int i = tid; i < BT_LAGLEN; i += 256) { sh.rwv[i] = rwv_tab[i]; sh.gwv[i] = 0.0f; }
-    for (int i = tid; i < 2 * BT_LAGLEN; i += 256) sh.phwv[i] = 1.0f;
-    if (tid == 0) {
-        sh.rp = 1.0f; sh.gp = 0.0f; sh.bp = 0.0f; sh.rp1 = 0.0f; sh.rp2 = 0.0f; sh.lastbeat = 0.0f;
-        sh.counter = 0; sh.flagstep = 0; sh.timesig = 0;
-    }
-    __syncthreads();
+    float dfwv[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) dfwv[q] = dfwv_tab[lane + 64 * q];
+    float gwv[2] = {0.0f, 0.0f};
+    if (lane == 0) sh.phout[BT_LAGLEN] = 0.0f;
+    // scalar state: every lane carries the same values
+    float gp_state = 0.0f, rp1 = 0.0f, rp2 = 0.0f, lastbeat = 0.0f;
+    int counter = 0, flagstep = 0, timesig = 0;
 
     const float g_var = 3.901f;
-    const int rayparam = 43;  // (60*22050/120/256) as u32
-    // beat-tracker runs happen at tempo frames 127 + 128*m
     const long n_b = sd.n_b;
-    const long n_runs = (n_b >= BT_STEP) ? (n_b - BT_STEP) / BT_STEP + 1 : 0;
+    long n_runs = (n_b >= BT_STEP) ? (n_b - BT_STEP) / BT_STEP + 1 : 0;  // runs happen at tempo frames 127 + 128 m
+    if (n_runs > (long)runs_pitch) n_runs = (long)runs_pitch;
 
-    for (long m = 0; m < n_runs && m < (long)runs_pitch; m++) {
-        // ---- dfframe for run m: s[128(m+1)-512+i], s[x] = 0 for x <= 0, thr[x-1] otherwise ----
-        for (int i = tid; i < BT_WINLEN; i += 256) {
-            const long xi = 128 * (m + 1) - 512 + i;
-            sh.dfframe[i] = (xi <= 0) ? 0.0f : thr[xi - 1];
-        }
-        __syncthreads();
-        // dfrev = reverse(dfframe * dfwv)
-        for (int i = tid; i < BT_WINLEN; i += 256) sh.dfrev[BT_WINLEN - 1 - i] = sh.dfframe[i] * sh.dfwv[i];
-        // vec_autocorr (:819-828): acf[L] = (sum_{j=L}^{511} f[j-L] f[j]) / (512 - L), summed in j order.  Thread t computes
-        // lags t and 511-t (513 products in total).  Written over i = j - L the first factor f[i] is the same for every
-        // lane, so for runs whose frame lies inside the song it comes from SCALAR loads of the thresholded series and
-        // only f[i + L] is an LDS read; the loops run to the wave-uniform bound and read the zero padding behind the
-        // frame instead of predicating (x + f[i] * 0 == x exactly, so the sums are bit-identical).
-        if (m >= 4) {
-            const float* __restrict__ fs = thr + (128 * (m + 1) - 512) - 1;  // fs[i] == dfframe[i], wave-uniform
-            const int wave = tid >> 6;
-            {
-                const float* va = sh.dfframe + tid;  // va[i] = f[i + lag], lag = tid
-                float acc = 0.0f;
-                const int na = BT_WINLEN - 64 * wave;
-                for (int i = 0; i < na; i += 16) {
-                    float sv[16];
+    // everything a run reads from memory is independent of the tracker's state: fetched one run ahead
+    struct RunIn {
+        float f[8];         // dfframe[lane + 64 q]
+        float g3[2], g4[2];  // comb sums at lags lane, lane + 64
+        float rp3, rp4, ts3, ts4;
+        float e[2], e1[2];   // 256-sample energies of tempo frames 127 + 128 m + (lane, lane + 64) and the following block
+    };
+    auto fetch = [&](long m, RunIn& r) {
 #pragma unroll
-                    for (int u = 0; u < 16; u++) sv[u] = fs[i + u];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) acc += sv[u] * va[i + u];
-                }
-                sh.acf[tid] = acc / (float)(BT_WINLEN - tid);
-            }
-            {
-                const int lag = BT_WINLEN - 1 - tid;
-                const float* vb = sh.dfframe + lag;
-                float acc = 0.0f;
-                const int nb = 64 * wave + 64;
-                for (int i = 0; i < nb; i += 16) {
-                    float sv[16];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) sv[u] = fs[i + u];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) acc += sv[u] * vb[i + u];
-                }
-                sh.acf[lag] = acc / (float)(BT_WINLEN - lag);
-            }
-        } else {
-            const int lag_a = tid, lag_b = BT_WINLEN - 1 - tid;
-            float acc = 0.0f;
-            for (int j = lag_a; j < BT_WINLEN; j++) acc += sh.dfframe[j - lag_a] * sh.dfframe[j];
-            sh.acf[lag_a] = acc / (float)(BT_WINLEN - lag_a);
-            acc = 0.0f;
-            for (int j = lag_b; j < BT_WINLEN; j++) acc += sh.dfframe[j - lag_b] * sh.dfframe[j];
-            sh.acf[lag_b] = acc / (float)(BT_WINLEN - lag_b);
+        for (int q = 0; q < 8; q++) {
+            const long xi = 128 * (m + 1) - 512 + lane + 64 * q;
+            r.f[q] = (xi <= 0) ? 0.0f : thr[xi - 1];
         }
-        __syncthreads();
-        // shift-invariant comb filterbank (:987-1003)
-        const int numelem = (sh.timesig == 0) ? 4 : sh.timesig;
-        if (tid < BT_LAGLEN) {
-            float v = 0.0f;
-            if (tid >= 1 && tid < BT_LAGLEN - 1) {
-                for (int a = 1; a <= numelem; a++)
-                    for (int b = 1; b < 2 * a; b++) {
-                        const int idx = tid * a + b - 1;
-                        if (idx < BT_WINLEN) v += sh.acf[idx] / (2.0f * (float)a - 1.0f);
-                    }
-            }
-            sh.acfout[tid] = v * sh.rwv[tid];
+        const float* pre = pre_song + (size_t)m * BT_PRE_STRIDE;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            r.g3[q] = pre[BT_PRE_G3 + lane + 64 * q];
+            r.g4[q] = pre[BT_PRE_G4 + lane + 64 * q];
+            const long t = 127 + 128 * m + lane + 64 * q;
+            r.e[q] = t < n_b ? en[t] : 1.0f;
+            r.e1[q] = t < n_b ? en[t + 1] : 1.0f;
         }
-        __syncthreads();
-        int maxindex = block_argmax_last(sh.acfout, BT_LAGLEN, sh.red_val, sh.red_idx);
-        if (tid == 0) {
-            if (maxindex > 0 && maxindex < BT_LAGLEN - 1) sh.rp = quad_peak_pos(sh.acfout, BT_LAGLEN, maxindex);
-            else sh.rp = (float)rayparam;
-        }
-        __syncthreads();
+        r.rp3 = pre[BT_PRE_RP3]; r.rp4 = pre[BT_PRE_RP4]; r.ts3 = pre[BT_PRE_TS3]; r.ts4 = pre[BT_PRE_TS4];
+    };
+    RunIn cur, nxt;
+    if (n_runs > 0) fetch(0, cur);
+
+    for (long m = 0; m < n_runs; m++) {
+        if (m + 1 < n_runs) fetch(m + 1, nxt);
+        // dfrev = reverse(dfframe * dfwv) (:975-980)
+#pragma unroll
+        for (int q = 0; q < 8; q++) sh.dfrev[BT_WINLEN - 1 - (lane + 64 * q)] = cur.f[q] * dfwv[q];
+        // the Rayleigh-weighted period for the current numelem (:983-1013)
+        const float rp = (timesig == 3) ? cur.rp3 : cur.rp4;
 
         // ---- checkstate (:1096-1227) ----
-        float gp = sh.gp;
-        if (gp > 0.0f) {  // uniform
-            if (tid < BT_LAGLEN) {
-                float v = 0.0f;
-                if (tid >= 1 && tid < BT_LAGLEN - 1) {
-                    for (int a = 1; a <= sh.timesig; a++)
-                        for (int b = 1; b < 2 * a; b++) {
-                            const int idx = tid * a + b - 1;
-                            if (idx < BT_WINLEN) v += sh.acf[idx];
-                        }
-                }
-                sh.acfout[tid] = v * sh.gwv[tid];
-            }
+        float gp = gp_state;
+        if (gp > 0.0f) {  // uniform; implies timesig in {3, 4}
+            const float x[2] = {(timesig == 3 ? cur.g3[0] : cur.g4[0]) * gwv[0], (timesig == 3 ? cur.g3[1] : cur.g4[1]) * gwv[1]};
+            sh.acfout[lane] = x[0];
+            sh.acfout[lane + 64] = x[1];
+            float best;
+            int maxindex;
+            wave_argmax_last(x, &best, &maxindex);
             __syncthreads();
-            maxindex = block_argmax_last(sh.acfout, BT_LAGLEN, sh.red_val, sh.red_idx);
             gp = quad_peak_pos(sh.acfout, BT_LAGLEN, maxindex);
         } else {
             gp = 0.0f;
         }
-        __syncthreads();
-        if (tid == 0) {
-            int counter = sh.counter, flagstep = sh.flagstep, flagconst = 0;
-            const float rp = sh.rp;
-            float rp1 = sh.rp1, rp2 = sh.rp2;
-            if (counter == 0) {
-                if (fabsf(gp - rp) > 2.0f * g_var) { flagstep = 1; counter = 3; }
-                else flagstep = 0;
-            }
-            if (counter == 1 && flagstep == 1) {
-                if (fabsf(2.0f * rp - rp1 - rp2) < g_var) { flagconst = 1; counter = 0; }
-                else { flagconst = 0; counter = 2; }
-            } else if (counter > 0) {
-                counter -= 1;
-            }
-            rp2 = rp1;
-            rp1 = rp;
-            float bp;
-            int phw_mode;  // 0 = flat, 1 = gaussian
-            if (flagconst) {
-                gp = rp;
-                sh.timesig = (int)bt_timesig(sh.acf, (long)gp);
-                bp = gp;
-                phw_mode = 0;
-            } else if (sh.timesig > 0) {
-                bp = gp;
-                phw_mode = ((float)BT_STEP > sh.lastbeat) ? 1 : 0;
-            } else {
-                bp = rp;
-                phw_mode = 0;
-            }
-            const float bp_for_phwv = bp;
-            while (bp > 0.0f && bp < 25.0f) bp *= 2.0f;
-            sh.counter = counter; sh.flagstep = flagstep; sh.gp = gp; sh.bp = bp; sh.rp1 = rp1; sh.rp2 = rp2;
-            sh.flagconst = flagconst; sh.phw_mode = phw_mode;
-            sh.red_val[0] = bp_for_phwv;
+        int flagconst = 0;
+        if (counter == 0) {
+            if (fabsf(gp - rp) > 2.0f * g_var) { flagstep = 1; counter = 3; }
+            else flagstep = 0;
         }
-        __syncthreads();
-        {
-            const float gpn = sh.gp, bpw = sh.red_val[0], lastbeat = sh.lastbeat;
-            if (sh.flagconst && tid < BT_LAGLEN) {
-                const float diff = (float)(tid + 1) - gpn;
-                sh.gwv[tid] = exp_f32(-0.5f * diff * diff / (g_var * g_var));
-            }
-            if (tid < 2 * BT_LAGLEN) {
-                if (sh.phw_mode == 1) {
-                    const float diff = 1.0f + (float)tid - (float)BT_STEP + lastbeat;
-                    sh.phwv[tid] = exp_f32(-0.5f * diff * diff / (bpw / 8.0f));
-                } else {
-                    sh.phwv[tid] = 1.0f;
-                }
-            }
+        if (counter == 1 && flagstep == 1) {
+            if (fabsf(2.0f * rp - rp1 - rp2) < g_var) { flagconst = 1; counter = 0; }
+            else { flagconst = 0; counter = 2; }
+        } else if (counter > 0) {
+            counter -= 1;
         }
-        __syncthreads();
-
-        const float bp = sh.bp;
-        uint32_t nbeats = 0;
-        if (bp == 0.0f) {  // uniform
-            if (tid < BT_STEP) sh.out[tid] = 0.0f;
-            __syncthreads();
+        rp2 = rp1;
+        rp1 = rp;
+        float bp;
+        int phw_mode;  // 0 = flat, 1 = gaussian
+        if (flagconst) {
+            gp = rp;
+            timesig = (int)((timesig == 3) ? cur.ts3 : cur.ts4);  // get_timesig(acf, gp) with gp = this run's rp
+            bp = gp;
+            phw_mode = 0;
+        } else if (timesig > 0) {
+            bp = gp;
+            phw_mode = ((float)BT_STEP > lastbeat) ? 1 : 0;
         } else {
-            // beat phase (:1025-1054)
+            bp = rp;
+            phw_mode = 0;
+        }
+        const float bpw = bp;
+        while (bp > 0.0f && bp < 25.0f) bp *= 2.0f;
+        gp_state = gp;
+        if (flagconst) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const float diff = (float)(lane + 64 * q + 1) - gp;
+                gwv[q] = exp_f32(-0.5f * diff * diff / (g_var * g_var));
+            }
+        }
+
+        uint32_t nbeats = 0;
+        if (bp != 0.0f) {  // uniform
+            // beat phase (:1025-1054): phout[i] is non-zero only for i < bp (< 128), where phwv applies
             const int kmax = (int)floorf((float)BT_WINLEN / bp);
-            for (int i = tid; i < BT_WINLEN; i += 256) {
+            __syncthreads();  // dfrev is complete
+            float ph[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int i = lane + 64 * q;
                 float v = 0.0f;
                 if ((float)i < bp) {
                     for (int k = 0; k < kmax; k++) {
@@ -350,53 +425,57 @@ __global__ __launch_bounds__(256) void beat_kernel(const SongDesc* __restrict__ 
                         if (idx < BT_WINLEN) v += sh.dfrev[idx];
                     }
                 }
-                if (i < 2 * BT_LAGLEN) v *= sh.phwv[i];
-                sh.phout[i] = v;
+                float w = 1.0f;
+                if (phw_mode == 1) {
+                    const float diff = 1.0f + (float)i - (float)BT_STEP + lastbeat;
+                    w = exp_f32(-0.5f * diff * diff / (bpw / 8.0f));
+                }
+                ph[q] = v * w;
+                sh.phout[i] = ph[q];
             }
+            float best;
+            int maxindex;
+            wave_argmax_last(ph, &best, &maxindex);
+            // the frame's remaining entries (128..511) are zero: the last of them wins unless an earlier one is positive
+            if (!(best > 0.0f)) maxindex = BT_WINLEN - 1;
             __syncthreads();
-            maxindex = block_argmax_last(sh.phout, BT_WINLEN, sh.red_val, sh.red_idx);
-            if (tid < BT_STEP) sh.out[tid] = 0.0f;
+            float phase;
+            if (maxindex >= BT_WINLEN - 1) phase = (float)BT_STEP - lastbeat;
+            else phase = quad_peak_pos(sh.phout, BT_WINLEN, maxindex);  // maxindex < 128: reads at most phout[128] == 0
+            phase += 1.0f;
+            int i = 1;
+            float beat = bp - phase;
+            if (((float)BT_STEP - lastbeat - phase) < -0.40f * bp) beat += bp;
+            while (beat + bp < 0.0f) beat += bp;
+            if (beat >= 0.0f && i < BT_STEP) { if (lane == 0) sh.out[i] = beat; i++; }
+            while (beat + bp <= (float)BT_STEP && i < BT_STEP) { beat += bp; if (lane == 0) sh.out[i] = beat; i++; }
+            lastbeat = beat;
+            nbeats = (uint32_t)i;
             __syncthreads();
-            if (tid == 0) {
-                float phase;
-                if (maxindex >= BT_WINLEN - 1) phase = (float)BT_STEP - sh.lastbeat;
-                else phase = quad_peak_pos(sh.phout, BT_WINLEN, maxindex);
-                phase += 1.0f;
-                int i = 1;
-                float beat = bp - phase;
-                if (((float)BT_STEP - sh.lastbeat - phase) < -0.40f * bp) beat += bp;
-                while (beat + bp < 0.0f) beat += bp;
-                if (beat >= 0.0f && i < BT_STEP) { sh.out[i] = beat; i++; }
-                while (beat + bp <= (float)BT_STEP && i < BT_STEP) { beat += bp; sh.out[i] = beat; i++; }
-                sh.lastbeat = beat;
-                sh.out[0] = (float)i;
-            }
-            __syncthreads();
-            nbeats = (uint32_t)sh.out[0];
         }
 
         // ---- frames 127+128m .. 127+128m+127 use out/bp of this run (Tempo::do_ :1418-1438) ----
-        if (tid == 0) sh.hit_count = 0;
-        __syncthreads();
-        if (tid < BT_STEP) {
-            const long t = 127 + 128 * m + tid;  // blockpos == tid
+        uint32_t hits = 0;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int j = lane + 64 * q;  // blockpos
+            const long t = 127 + 128 * m + j;
+            float tempo = 0.0f;
             if (t < n_b) {
-                float tempo = 0.0f;
                 for (uint32_t i = 1; i < nbeats; i++) {
                     const float beat_pos = sh.out[i];
-                    if (tid == (int)floorf(beat_pos)) {
+                    if (j == (int)floorf(beat_pos)) {
                         tempo = beat_pos - floorf(beat_pos);
                         // is_silence over the 512-sample window analyze() passed: x[256t, 256t+512),
                         // i.e. the 256-sample energy blocks t and t+1
-                        const float level = (en[t] + en[t + 1]) / 512.0f;
+                        const float level = (cur.e[q] + cur.e1[q]) / 512.0f;
                         if (10.0f * log10f(level) < -90.0f) tempo = 0.0f;
                     }
                 }
-                if (tempo > 0.0f) atomicAdd(&sh.hit_count, 1u);
             }
+            hits += (uint32_t)__popcll(__ballot(tempo > 0.0f));
         }
-        __syncthreads();
-        if (tid == 0) {
+        if (lane == 0) {
             // BeatTracking::get_bpm (:1231-1239)
             float bpm = 0.0f;
             if (bp != 0.0f) {
@@ -405,29 +484,28 @@ __global__ __launch_bounds__(256) void beat_kernel(const SongDesc* __restrict__ 
                 bpm = 60.0f / period_s;
             }
             rbpm[m] = bpm;
-            rcnt[m] = sh.hit_count;
+            rcnt[m] = hits;
         }
-        __syncthreads();
+        __syncthreads();  // out / dfrev / phout are rewritten by the next run
+        cur = nxt;
     }
+    __threadfence_block();
+    __syncthreads();
 
     // ---- BPMDesc::get_value (src/temporal.rs:66-77): Midpoint median of the pushed bpms ----
-    __shared__ uint32_t s_total;
-    __shared__ float s_lo, s_hi;
-    const long runs = (n_runs < (long)runs_pitch) ? n_runs : (long)runs_pitch;
-    if (tid == 0) {
-        uint32_t tot = 0;
-        for (long m = 0; m < runs; m++) tot += rcnt[m];
-        s_total = tot;
-        s_lo = 0.0f; s_hi = 0.0f;
-    }
-    __syncthreads();
-    const uint32_t total = s_total;
+    const long runs = n_runs;
+    uint32_t tot = 0;
+    for (long m = lane; m < runs; m += WAVE) tot += rcnt[m];
+    const uint32_t total = wave_sum(tot);
     if (total == 0) {
-        if (tid == 0) { tempo_out[s].tempo = -1.0f; tempo_out[s].n_bpms = 0; }
+        if (lane == 0) { tempo_out[s].tempo = -1.0f; tempo_out[s].n_bpms = 0; }
         return;
     }
     const uint32_t r_lo = (total - 1) / 2, r_hi = (total - 1) - r_lo == r_lo ? r_lo : r_lo + 1;
-    for (long m = tid; m < runs; m += 256) {
+    // equal values yield the same number, so "any lane that holds the order statistic" is well defined
+    float lo = 0.0f, hi = 0.0f;
+    bool has_lo = false, has_hi = false;
+    for (long m = lane; m < runs; m += WAVE) {
         const uint32_t c = rcnt[m];
         if (c == 0) continue;
         const float v = rbpm[m];
@@ -439,11 +517,13 @@ __global__ __launch_bounds__(256) void beat_kernel(const SongDesc* __restrict__ 
             if (vq < v) less += cq;
             if (vq <= v) leq += cq;
         }
-        if (less <= r_lo && r_lo < leq) s_lo = v;  // equal values write the same number: benign
-        if (less <= r_hi && r_hi < leq) s_hi = v;
+        if (less <= r_lo && r_lo < leq) { lo = v; has_lo = true; }
+        if (less <= r_hi && r_hi < leq) { hi = v; has_hi = true; }
     }
-    __syncthreads();
-    if (tid == 0) {
+    const uint64_t m_lo = __ballot(has_lo), m_hi = __ballot(has_hi);
+    const float s_lo = m_lo ? __shfl(lo, __ffsll((unsigned long long)m_lo) - 1, WAVE) : 0.0f;
+    const float s_hi = m_hi ? __shfl(hi, __ffsll((unsigned long long)m_hi) - 1, WAVE) : 0.0f;
+    if (lane == 0) {
         const float median = s_lo + (s_hi - s_lo) / 2.0f;
         tempo_out[s].tempo = 2.0f * (median - 0.0f) / (206.0f - 0.0f) - 1.0f;
         tempo_out[s].n_bpms = total;
@@ -452,8 +532,12 @@ __global__ __launch_bounds__(256) void beat_kernel(const SongDesc* __restrict__ 
 
 void launch_beat(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.n_songs == 0) return;
-    hipLaunchKernelGGL(beat_kernel, dim3(b.n_songs), dim3(256), 0, st, b.songs, w.thresholded, w.e256, t.bt_rwv,
-                       t.bt_dfwv, w.run_bpm, w.run_cnt, w.runs_pitch, w.tempo);
+    const uint32_t max_runs = b.max_nb >= (uint32_t)BT_STEP ? (b.max_nb - BT_STEP) / BT_STEP + 1 : 0;
+    if (max_runs > 0)
+        hipLaunchKernelGGL(beat_acf_kernel, dim3(max_runs, b.n_songs), dim3(128), 0, st, b.songs, w.thresholded, t.bt_rwv,
+                           w.bt_pre);
+    hipLaunchKernelGGL(beat_track_kernel, dim3(b.n_songs), dim3(64), 0, st, b.songs, w.thresholded, w.e256, t.bt_dfwv,
+                       w.bt_pre, w.run_bpm, w.run_cnt, w.runs_pitch, w.tempo);
 }
 
 }  // namespace bg

@@ -50,7 +50,7 @@ size_t song_ws_bytes(const SongDesc& d) {
     b += (size_t)d.n_c * CAND_BUDGET_PER_FRAME * 9;
     b += (size_t)d.n_c * (PIP_MAX_PER_FRAME * 4 + 4);
     b += ((size_t)d.n_c / CH_TILE + 1) * 80;
-    b += ((size_t)d.n_b / BT_STEP + 2) * 8;
+    b += ((size_t)d.n_b / BT_STEP + 2) * (8 + BT_PRE_STRIDE * 4);
     return b + 4096;
 }
 
@@ -90,6 +90,7 @@ Workspace carve(uint8_t* base, uint32_t ns, const ChunkTotals& t, size_t* bytes)
     w.tempo = m.take<TempoState>(ns);
     w.run_bpm = m.take<float>((size_t)ns * t.max_runs); w.run_cnt = m.take<uint32_t>((size_t)ns * t.max_runs);
     w.runs_pitch = t.max_runs;
+    w.bt_pre = m.take<float>((size_t)(t.tot_b / BT_STEP + ns + 1) * BT_PRE_STRIDE);
     w.summary = m.take<float>((size_t)ns * 16);
     *bytes = m.off + 4096;
     return w;
@@ -97,7 +98,7 @@ Workspace carve(uint8_t* base, uint32_t ns, const ChunkTotals& t, size_t* bytes)
 
 int ensure_slot_events(ChunkSlot& s) {
     if (s.ev_free) return BLISSGPU_OK;
-    hipEvent_t* evs[] = {&s.ev_start, &s.ev_fork, &s.ev_stft, &s.ev_tune, &s.ev_sum, &s.ev_chroma, &s.ev_desc, &s.ev_free};
+    hipEvent_t* evs[] = {&s.ev_start, &s.ev_fork, &s.ev_stft, &s.ev_sel, &s.ev_tune, &s.ev_sum, &s.ev_chroma, &s.ev_desc, &s.ev_free};
     for (hipEvent_t* e : evs) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     return BLISSGPU_OK;
 }
@@ -202,10 +203,18 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
     if (multi) {
         HIP_TRY(hipEventRecord(slot.ev_stft, st));
         HIP_TRY(hipStreamWaitEvent(sc, slot.ev_stft, 0));
-        if (beat_late) HIP_TRY(hipStreamWaitEvent(sb, slot.ev_stft, 0));
     }
-    if (beat_late) { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
     { Prof p(c, K_TUNE_SELECT, sc); launch_tune_select(b, w, sc); }
+    if (beat_late) {
+        // behind tune_select, not beside it: the beat tracker's 1024 resident workgroups otherwise hold that 20 us kernel
+        // (the head of the critical tuning -> chroma chain) for 2.2 ms (kernel timeline, tests/tools/timeline.sh)
+        if (multi) {
+            HIP_TRY(hipEventRecord(slot.ev_sel, sc));
+            HIP_TRY(hipStreamWaitEvent(sb, slot.ev_sel, 0));
+        }
+        Prof p(c, K_BEAT, sb);
+        launch_beat(b, w, c->tables, sb);
+    }
     { Prof p(c, K_TUNE_PASS2, sc); launch_tune_pass2(b, w, sc); }
     { Prof p(c, K_TUNE_FINAL, sc); launch_tune_final(b, w, sc); }
     if (multi) HIP_TRY(hipEventRecord(slot.ev_tune, sc));
@@ -238,7 +247,7 @@ namespace bg {
 void scheduler_release(blissgpu_ctx* c) {
     for (ChunkSlot& s : c->slot) {
         s.slab.release(); s.desc.release(); s.h_desc.release();
-        hipEvent_t evs[] = {s.ev_start, s.ev_fork, s.ev_stft, s.ev_tune, s.ev_sum, s.ev_chroma, s.ev_desc, s.ev_free};
+        hipEvent_t evs[] = {s.ev_start, s.ev_fork, s.ev_stft, s.ev_sel, s.ev_tune, s.ev_sum, s.ev_chroma, s.ev_desc, s.ev_free};
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
         s = ChunkSlot{};
