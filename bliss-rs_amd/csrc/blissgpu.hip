@@ -73,7 +73,7 @@ int build_tables(blissgpu_ctx* c) {
     if ((rc = upload(&c->hannz512, hannz))) return rc;
     if ((rc = upload(&c->bt_rwv, rwv))) return rc;
     if ((rc = upload(&c->bt_dfwv, dfwv))) return rc;
-    const size_t bank_elems = (size_t)(N_TUNING + 1) * BANK_ROWS * CBINS_PAD;
+    const size_t bank_elems = (size_t)(N_TUNING + 1) * BANK_ROWS * BANK_PITCH;
     HIP_TRY(hipMalloc((void**)&c->chroma_bank, bank_elems * sizeof(double)));
     launch_chroma_bank(c->chroma_bank, c->own_stream);
     HIP_TRY(hipGetLastError());

@@ -18,8 +18,9 @@ constexpr int HOP_B = 256;                // BPMDesc::HOP_SIZE
 constexpr int W8192 = 8192;               // ChromaDesc::WINDOW_SIZE
 constexpr int HOP_C = 2205;               // src/chroma.rs:74
 constexpr int CBINS = W8192 / 2 + 1;      // 4097
-constexpr int CBINS_PAD = 4112;           // row pitch (multiple of 16 bins) of the stored spectrogram and of the filter bank
-constexpr int BANK_ROWS = 16;             // 12 chroma rows padded to the MFMA M=16
+constexpr int CBINS_PAD = 4128;           // row pitch of the stored spectrogram: 129 lines of 128 bytes, so every row starts on a line
+constexpr int BANK_PITCH = CBINS_PAD;     // row pitch of the filter bank (zero beyond bin 4096)
+constexpr int BANK_ROWS = 12;             // chroma classes
 constexpr int LOUD_W = 1024;              // LoudnessDesc::WINDOW_SIZE
 constexpr int MIN_SAMPLES = 8192;         // src/song/mod.rs:417-430
 constexpr int N_TUNING = 100;             // pitch_tuning histogram bins at resolution 0.01
@@ -73,7 +74,7 @@ struct DeviceTables {   // constant tables, built once per context
     const float2* tw512;      // exp(-2*pi*i*k/512),  k < 512
     const float* hann8192;    // periodic Hann, src/utils.rs:37-39
     const float* hannz512;    // hanningz, src/aubio.rs:151-154
-    const double* chroma_bank;// [N_TUNING+1][BANK_ROWS][CBINS_PAD] chroma filters (zero padded); slot N_TUNING = tuning 0.0
+    const double* chroma_bank;// [N_TUNING+1][BANK_ROWS][BANK_PITCH] chroma filters (zero padded); slot N_TUNING = tuning 0.0
     const float* bt_rwv;      // [128] Rayleigh weighting, src/aubio.rs:925-930
     const float* bt_dfwv;     // [512] detection-function weighting, src/aubio.rs:933-936
 };

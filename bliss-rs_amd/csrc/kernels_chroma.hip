@@ -26,6 +26,8 @@
 namespace bg {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // chroma filter bank
@@ -39,10 +41,10 @@ __global__ __launch_bounds__(256) void chroma_bank_kernel(double* __restrict__ b
 #pragma clang fp contract(off)
     const int slot = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= CBINS_PAD) return;
-    double* out = bank + (size_t)slot * BANK_ROWS * CBINS_PAD;
+    if (k >= BANK_PITCH) return;
+    double* out = bank + (size_t)slot * BANK_ROWS * BANK_PITCH;
     if (k >= CBINS) {
-        for (int r = 0; r < BANK_ROWS; r++) out[(size_t)r * CBINS_PAD + k] = 0.0;
+        for (int r = 0; r < BANK_ROWS; r++) out[(size_t)r * BANK_PITCH + k] = 0.0;
         return;
     }
     const double tuning = tuning_of_slot(slot);
@@ -70,12 +72,12 @@ __global__ __launch_bounds__(256) void chroma_bank_kernel(double* __restrict__ b
     for (int r = 0; r < BANK_ROWS; r++) {
         double v = 0.0;
         if (r < 12) v = (w[(r + 3) % 12] / l2) * g;  // np.roll(-3) along the chroma axis
-        out[(size_t)r * CBINS_PAD + k] = v;
+        out[(size_t)r * BANK_PITCH + k] = v;
     }
 }
 
 void launch_chroma_bank(double* bank, hipStream_t st) {
-    hipLaunchKernelGGL(chroma_bank_kernel, dim3((CBINS_PAD + 255) / 256, N_TUNING + 1), dim3(256), 0, st, bank);
+    hipLaunchKernelGGL(chroma_bank_kernel, dim3((BANK_PITCH + 255) / 256, N_TUNING + 1), dim3(256), 0, st, bank);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -245,7 +247,7 @@ constexpr int LHIST_BINS = 512;  // 16 octaves of 32 coarse bins
 constexpr int EX1_PITCH = 257;   // k1-major rows of 256 (+1): the 16 lanes of a ds_read2_b64 group tile all 32 banks
 constexpr int EX2_PITCH = 272;   // j1-major rows of 256 (+16): shifts odd rows by 32 banks
 constexpr int STFT_LDS = 16 * EX2_PITCH;  // float2 elements (34 816 B)
-constexpr int MAGS_TOP = 2 * 4096;        // word index (of the exchange buffer) where magnitude words 4096..4111 live
+constexpr int MAGS_TOP = 2 * 4096;        // word index (of the exchange buffer) where magnitude words 4096..4127 live
 
 // W_32^j = (cos, -sin)(2 pi j / 32), j < 8
 __device__ constexpr float CONST_COS32[8] = {1.0f, 0.98078528040323044f, 0.92387953251128674f, 0.83146961230254524f,
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         if (has_next) load_frame(f + 1, v);
         mx = wave_max_dpp(mx);
         // The split only reads the UPPER half of the exchange buffer (complex slots 2049..4095 = bytes 16 392..32 767);
-        // the row of 4112 magnitudes goes into the dead lower half (words 0..4095) and, for bin 4096 and the zero padding,
+        // the row of 4128 magnitudes goes into the dead lower half (words 0..4095) and, for bin 4096 and the zero padding,
         // into the 2 KB behind the upper half -- no barrier between the split reads and these writes.
         float* mags = reinterpret_cast<float*>(lds);
         float* mags_top = mags + MAGS_TOP - 4096;  // mags_top[4096 + i] = word MAGS_TOP + i
@@ -906,7 +908,14 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
                                                      const double* __restrict__ bank,
                                                      const TuningState* __restrict__ tuning,
                                                      double* __restrict__ chroma_part) {
-    __shared__ double tile_c[4][4][16][13];
+    // one object so that the order is fixed: the DMA ring lies in the first 64 KB of the workgroup's LDS
+    __shared__ struct {
+        double2_t a_ring[4][3][3][64];  // [wavefront][ring slot][row group][DMA lane]: 16 bytes each
+        double tile_c[4][4][16][13];
+    } sm;
+    auto& a_ring = sm.a_ring;
+    auto& tile_c = sm.tile_c;
+    static_assert(sizeof(sm.a_ring) <= 65536, "DMA targets within the first 64 KB");
     const uint32_t s = find_segment(pfx_cw, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
     const int lane = lane_id(), wave = wave_id();
@@ -918,59 +927,140 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
     const int slot = (tidx < 0) ? N_TUNING : tidx;
     const uint32_t f0 = tile64 * CH_TILE;
 
-    const double* __restrict__ arow = bank + ((size_t)slot * BANK_ROWS + i16) * CBINS_PAD + 4 * g;
+    // The contraction runs on v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 blocks per instruction.  A block is a
+    // group of four frames, every block takes the SAME four filter rows, and three instructions (rows 0-3, 4-7, 8-11)
+    // cover the 12 chroma classes exactly -- the 16x16x4 form spends a quarter of its rows on padding and, on this
+    // chip, runs at 60 instead of 77 TFLOP/s (tests/tools/probes/mfma_probe.hip: 4.1 vs 2.4 ms for this kernel's work).
+    // Operand layout (tests/tools/probes/mfma_layout.hip): lane = x + 4 blk + 16 y with A: x = row, y = k;
+    // B: x = frame within the block, y = k; D: x = frame, y = row.  So lane % 16 is the frame of a 16-frame sub-tile
+    // and lane / 16 the k slot, exactly as in the 16x16x4 form, and a lane's filter rows are (lane % 4) + {0, 4, 8}.
+    //
+    // K is consumed in an order chosen for the memory system, not 0, 1, 2, ...: within a 32-bin (128-byte) block the four
+    // lanes of a frame sit 32 bytes apart and take two 16-byte pieces each, so EVERY load instruction touches both
+    // 64-byte halves of its 16 lines.  With the natural order (lane g on bins 4g..4g+3: 64 contiguous bytes per frame and
+    // instruction) the same bytes arrive at 4.7 TB/s instead of 5.9 (tests/tools/probes/bw_probe.hip).  The filter (A)
+    // fragments follow the same permutation, so the sum over K has the same terms.
     const float* brow[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         uint32_t fj = f0 + 16 * q + i16;
         if (fj >= sd.n_c) fj = sd.n_c - 1;  // clamped rows are computed and discarded
-        brow[q] = spec + (sd.c_off + fj) * (size_t)CBINS_PAD + 4 * g;
+        brow[q] = spec + (sd.c_off + fj) * (size_t)CBINS_PAD + 8 * g;
     }
-    // two independent accumulator chains per sub-tile so consecutive MFMAs do not wait on each other
-    double4_t acc[4][2];
+    // acc[q][r]: rows 4r + (lane / 16) of the 16-frame sub-tile q; twelve independent chains
+    double acc[4][3];
 #pragma unroll
-    for (int q = 0; q < 4; q++) { acc[q][0] = double4_t{0.0, 0.0, 0.0, 0.0}; acc[q][1] = double4_t{0.0, 0.0, 0.0, 0.0}; }
-    // K loop in groups of KU steps: all loads of a group are issued before its first MFMA, so the later steps'
-    // loads are in flight while the earlier steps' MFMAs run (a load -> drain -> MFMA loop per step cannot cover
-    // the HBM latency with two waves per SIMD).  No loaded value is carried across iterations: that form made
-    // the compiler shuttle the 64 accumulator registers between VGPRs and AGPRs every step.
-    constexpr int KSTEPS = CBINS_PAD / 16, KU = 4;
-    auto k_group = [&](int st0, auto nsteps) {
-        constexpr int NS = decltype(nsteps)::value;
-        double4_t a[NS];
-        float4 b[NS][4];
+    for (int q = 0; q < 4; q++)
 #pragma unroll
-        for (int u = 0; u < NS; u++) {
-            a[u] = *reinterpret_cast<const double4_t*>(arow + 16 * (st0 + u));
+        for (int r = 0; r < 3; r++) acc[q][r] = 0.0;
+    // K loop in 32-bin blocks (two 16-bin steps of four k slots), software-pipelined by hand.
+    //  * The spectrogram (B) comes from HBM into a ring of three register blocks: two blocks (2 x 8 loads) are in flight
+    //    behind the one being multiplied -- a block is only 96 MFMAs = ~0.6 us of matrix pipe, far less than the loaded
+    //    HBM latency.
+    //  * The filter (A) comes from the L2-resident bank.  Vector-memory loads retire in order, so an A fetch issued after
+    //    a B prefetch could not be waited for without draining that prefetch; and a second register ring for A does not
+    //    fit.  A block's 3 KB of filter values therefore travel global -> LDS directly (no registers), two blocks ahead,
+    //    into a private three-slot ring per wavefront, and are read back (own counter) at the start of their block.
+    // No branch in the loop: the fetches past the end re-read the last block.
+    struct BBlock { float4_t b[2][4]; };
+    constexpr int KBLOCKS = CBINS_PAD / 32;
+    static_assert(CBINS_PAD % 32 == 0 && BANK_PITCH == CBINS_PAD && KBLOCKS % 3 == 0, "the loop below handles three blocks per trip");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // lane L of a DMA instruction fetches 16 bytes = bins 8 gd + 4 ud + 2 hd (+0, +1) of filter row 4 r + id
+    const int id = lane & 3, gd = (lane >> 2) & 3, hd = (lane >> 4) & 1, ud = lane >> 5;
+    const double* __restrict__ a_src = bank + ((size_t)slot * BANK_ROWS + id) * BANK_PITCH + 8 * gd + 4 * ud + 2 * hd;
+    auto a_dma = [&](int blk, int ring) {
+        const int k0 = 32 * (blk < KBLOCKS ? blk : KBLOCKS - 1);
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                b[u][q] = *reinterpret_cast<const float4*>(brow[q] + 16 * (st0 + u));
-        }
+        for (int r = 0; r < 3; r++)
+            __builtin_amdgcn_global_load_lds(a_src + (size_t)4 * r * BANK_PITCH + k0, &a_ring[wave_u][ring][r][0], 16, 0, 0);
+    };
+    // lane (i, blk, g) reads rows 4 r + i at bins 8 g + 4 u + 2 h: DMA lane i + 4 g + 16 h + 32 u.  The read is an asm
+    // block: the compiler's dependence tracking for global->LDS transfers drains the WHOLE vector memory queue before a
+    // ds_read of such a buffer (it cannot tell the ring slots apart), which would also wait for the spectrogram
+    // prefetches.  wait_block() below has made sure the slot's DMA has landed.
+    const uint32_t a_rd = (uint32_t)(uintptr_t)&a_ring[wave_u][0][0][(lane & 3) + 4 * g];
+    struct AStep { double2_t a[3][2]; };  // [row group][k pair]
+    auto a_read = [&](int ring, int u, AStep& as) {
+        const uint32_t addr = a_rd + (uint32_t)ring * (uint32_t)sizeof(a_ring[0][0]) + 512u * (uint32_t)u;
+        asm volatile(
+            "ds_read_b128 %0, %6\n\t"
+            "ds_read_b128 %1, %6 offset:256\n\t"
+            "ds_read_b128 %2, %6 offset:1024\n\t"
+            "ds_read_b128 %3, %6 offset:1280\n\t"
+            "ds_read_b128 %4, %6 offset:2048\n\t"
+            "ds_read_b128 %5, %6 offset:2304\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(as.a[0][0]), "=&v"(as.a[0][1]), "=&v"(as.a[1][0]), "=&v"(as.a[1][1]), "=&v"(as.a[2][0]), "=&v"(as.a[2][1])
+            : "v"(addr));
+    };
+    // The spectrogram loads are asm statements too, so that NO wait in the loop is the compiler's: with global->LDS
+    // transfers in the queue its counter tracking falls back to vmcnt(0) for ordinary loads as well.
+    auto b_load = [&](int blk, BBlock& bb) {
+        const int k0 = 32 * (blk < KBLOCKS ? blk : KBLOCKS - 1);
 #pragma unroll
-        for (int u = 0; u < NS; u++) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const double b0 = (double)b[u][q].x * (double)b[u][q].x, b1 = (double)b[u][q].y * (double)b[u][q].y;
-                const double b2 = (double)b[u][q].z * (double)b[u][q].z, b3 = (double)b[u][q].w * (double)b[u][q].w;
-                acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b0, acc[q][0], 0, 0, 0);
-                acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b1, acc[q][1], 0, 0, 0);
-                acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].z, b2, acc[q][0], 0, 0, 0);
-                acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].w, b3, acc[q][1], 0, 0, 0);
-            }
+        for (int q = 0; q < 4; q++) {
+            const float* p = brow[q] + k0;
+            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                         : "=&v"(bb.b[0][q]), "=&v"(bb.b[1][q])
+                         : "v"(p));
         }
     };
+    // Everything issued before the spectrogram block B(j+1) has landed: in program order that is A(j) [3 transfers],
+    // B(j) [8 loads] and A(j+1) [3]; only B(j+1)'s 8 loads may still be in flight.  The block's registers pass through
+    // the statement so that none of their uses can be scheduled above it.
+    auto wait_block = [&](BBlock& bb) {
+        asm volatile("s_waitcnt vmcnt(8)"
+                     : "+v"(bb.b[0][0]), "+v"(bb.b[0][1]), "+v"(bb.b[0][2]), "+v"(bb.b[0][3]), "+v"(bb.b[1][0]),
+                       "+v"(bb.b[1][1]), "+v"(bb.b[1][2]), "+v"(bb.b[1][3]));
+    };
+    auto step_mma = [&](const AStep& as, const BBlock& bb, int u) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {  // k slot of the lane's four consecutive bins: twelve independent MFMAs per slot
+            double sq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double x = (double)bb.b[u][q][e];
+                sq[q] = x * x;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+                    acc[q][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(as.a[r][e >> 1][e & 1], sq[q], acc[q][r], 0, 0, 0);
+        }
+    };
+    // one block: wait for its operands, read the filter values of its first step, THEN issue the transfers for the block
+    // two ahead (program order = retirement order: the next wait must not include them), then the 96 MFMAs
+    auto block = [&](int ring, BBlock& bcur, int blk_next, int ring_next, BBlock& bnext) {
+        AStep as;
+        wait_block(bcur);
+        a_read(ring, 0, as);
+        a_dma(blk_next, ring_next);
+        b_load(blk_next, bnext);
+        step_mma(as, bcur, 0);
+        a_read(ring, 1, as);
+        step_mma(as, bcur, 1);
+    };
+    BBlock b0, b1, b2;
+    a_dma(0, 0);
+    b_load(0, b0);
+    a_dma(1, 1);
+    b_load(1, b1);
 #pragma unroll 1
-    for (int st = 0; st + KU <= KSTEPS; st += KU) k_group(st, std::integral_constant<int, KU>{});
-    static_assert(KSTEPS % KU == 1, "tail below handles exactly one step");
-    k_group(KSTEPS - 1, std::integral_constant<int, 1>{});
+    for (int blk = 0; blk < KBLOCKS; blk += 3) {
+        block(0, b0, blk + 2, 2, b2);
+        block(1, b1, blk + 3, 0, b0);
+        block(2, b2, blk + 4, 1, b1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the (unused) fetches past the end
     // Epilogue on all 64 lanes at once: the four C tiles go through LDS so that lane 16 q + i owns frame 16 q + i
     // (12 chroma values), instead of four passes of the f64 exp / template arithmetic on 16 active lanes each.
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const double4_t cacc = acc[q][0] + acc[q][1];
         // C[row = g + 4r][col = i16]: rows are chroma classes, columns are frames
 #pragma unroll
-        for (int r = 0; r < 3; r++) tile_c[wave][q][i16][g + 4 * r] = cacc[r];
+        for (int r = 0; r < 3; r++) tile_c[wave][q][i16][g + 4 * r] = acc[q][r];
     }
     __builtin_amdgcn_wave_barrier();
     double feat[10];

@@ -127,7 +127,7 @@ class Context:
         if n.value:
             _ffi.check(self._L.blissgpu_debug_fetch(self._h, code, song, C.c_void_p(out.ctypes.data), n.value, C.byref(n)))
         if what == "spectrogram":
-            out = out.reshape(-1, 4112)[:, :4097]
+            out = out.reshape(-1, 4128)[:, :4097]
         return out
 
     # ---- distances ----

@@ -252,7 +252,7 @@ uint64_t blissgpu_debug_last_chunks(blissgpu_ctx *ctx);
 #define BLISSGPU_DEBUG_THRESHOLDED 4   /* f32[n_b]  PeakPicker thresholded values (:757) */
 #define BLISSGPU_DEBUG_RUN_BPM 5       /* f32[runs] BeatTracking::get_bpm after each run (:1231-1239) */
 #define BLISSGPU_DEBUG_RUN_COUNT 6     /* u32[runs] beats BPMDesc recorded while that bpm was current */
-#define BLISSGPU_DEBUG_SPECTROGRAM 7   /* f32[n_c][4112] STFT magnitudes, 4097 valid per row (src/utils.rs:26-64) */
+#define BLISSGPU_DEBUG_SPECTROGRAM 7   /* f32[n_c][4128] STFT magnitudes, 4097 valid per row (src/utils.rs:26-64) */
 #define BLISSGPU_DEBUG_ENERGY256 8     /* f32[ceil(n/256)] sum of squares per 256 samples */
 #define BLISSGPU_DEBUG_CROSSINGS256 9  /* u32[ceil(n/256)] zero crossings per 256 samples */
 #define BLISSGPU_DEBUG_PITCH_HIST 10   /* u32[100] pitch-residue histogram (peaks above the median's coarse bin) */
