@@ -192,11 +192,12 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
         HIP_TRY(hipStreamWaitEvent(sb, slot.ev_fork, 0));
     }
     { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
-    // The beat tracker is one 256-thread workgroup per song: beside the FFT-8192 kernel every one of them displaces an
-    // FFT-8192 workgroup (that kernel fills the LDS and the register file).  In a multi-chunk batch that is still the
-    // best place (measured on the 6 250-song mixed corpus: 452 vs 472 ms) -- everything later belongs to the next chunk;
-    // a batch of ONE chunk runs it behind the FFT-8192 kernel, beside the tuning / chroma kernels (42.6 vs 43.0 ms per
-    // 1024 songs, and the FFT-8192 kernel keeps its undisturbed 18 ms).
+    // The beat tracker (the parallel autocorrelation kernel + the one-wavefront-per-song state machine): beside the
+    // FFT-8192 kernel its workgroups displace FFT-8192 workgroups (that kernel fills the LDS and the register file:
+    // 18.9 instead of 17.3 ms).  In a multi-chunk batch that is still as good a place as any (machine time is conserved;
+    // 427 vs 426 ms on the 6 250-song mixed corpus) and keeps the chunk's tail short; a batch of ONE chunk runs it behind
+    // the FFT-8192 kernel, where the latency-bound tuning kernels leave the machine half empty (39.5 vs 40.1 ms per 1024
+    // songs).
     const bool beat_late = c->tail_mode == 1 || (c->tail_mode < 0 && only_chunk);
     if (!beat_late) { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
     { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st); }
@@ -206,8 +207,8 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
     }
     { Prof p(c, K_TUNE_SELECT, sc); launch_tune_select(b, w, sc); }
     if (beat_late) {
-        // behind tune_select, not beside it: the beat tracker's 1024 resident workgroups otherwise hold that 20 us kernel
-        // (the head of the critical tuning -> chroma chain) for 2.2 ms (kernel timeline, tests/tools/timeline.sh)
+        // behind tune_select, not beside it: a kernel with resident workgroups on every CU holds that 20 us kernel (the
+        // head of the critical tuning -> chroma chain) for milliseconds (kernel timeline, tests/tools/timeline.sh)
         if (multi) {
             HIP_TRY(hipEventRecord(slot.ev_sel, sc));
             HIP_TRY(hipStreamWaitEvent(sb, slot.ev_sel, 0));
