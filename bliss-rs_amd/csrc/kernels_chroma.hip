@@ -747,7 +747,8 @@ void launch_tune_pass2(const Batch& b, const Workspace& w, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // for_each(fn) calls fn(magnitude, pitch bin) for every candidate of the song, spread over the 256 threads
 template <typename ForEach>
-__device__ uint64_t block_radix_select(ForEach&& for_each, uint32_t rank, uint32_t* hist, uint32_t* s_digit, uint32_t* s_rank) {
+__device__ uint64_t block_radix_select(ForEach&& for_each, uint32_t rank, uint32_t* hist, uint32_t* s_digit, uint32_t* s_rank,
+                                       uint32_t* s_wave) {
     const int tid = threadIdx.x;
     uint64_t prefix = 0, mask = 0;
     for (int shift = 56; shift >= 0; shift -= 8) {
@@ -755,17 +756,35 @@ __device__ uint64_t block_radix_select(ForEach&& for_each, uint32_t rank, uint32
         __syncthreads();
         for_each([&](double mag, int) {
             const uint64_t k = f64_key(mag);
-            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFF], 1u);
+            const bool in = (k & mask) == prefix;
+            const uint32_t d = (uint32_t)(k >> shift) & 0xFFu;
+            // the candidates share their leading bytes (they come from one or two coarse magnitude bins): a wavefront whose
+            // keys all carry the same digit adds its count once instead of serialising 64 atomics on one LDS word
+            const uint64_t m = __ballot(in);
+            if (m != 0) {
+                const int first = __ffsll((unsigned long long)m) - 1;
+                const uint32_t d0 = (uint32_t)__shfl((int)d, first, WAVE);
+                if (__ballot(in && d == d0) == m) {
+                    if (lane_id() == first) atomicAdd(&hist[d0], (uint32_t)__popcll(m));
+                } else if (in) {
+                    atomicAdd(&hist[d], 1u);
+                }
+            }
         });
         __syncthreads();
-        if (tid == 0) {
-            uint32_t acc = 0, d = 0;
-            for (; d < 256; d++) {
-                if (rank < acc + hist[d]) break;
-                acc += hist[d];
+        {
+            // digit d with below(d) <= rank < below(d) + hist[d]: one thread per digit, prefix sums by wave scan (a serial
+            // walk over the 256 LDS counters by one thread cost ~25 us per pass, eight passes per song)
+            const uint32_t h = hist[tid];
+            const uint32_t incl = wave_scan_incl_u32(h);
+            if (lane_id() == 63) s_wave[wave_id()] = incl;
+            __syncthreads();
+            uint32_t below = incl - h;
+            for (int w = 0; w < wave_id(); w++) below += s_wave[w];
+            if (h != 0 && below <= rank && rank < below + h) {  // exactly one digit qualifies (rank < number of keys)
+                *s_digit = (uint32_t)tid;
+                *s_rank = rank - below;
             }
-            *s_digit = d;
-            *s_rank = rank - acc;
         }
         __syncthreads();
         prefix |= (uint64_t)(*s_digit) << shift;
@@ -786,7 +805,7 @@ __global__ __launch_bounds__(256) void tune_final_kernel(const SongDesc* __restr
                                                          const uint32_t* __restrict__ peak_rec,
                                                          const uint32_t* __restrict__ peak_cnt) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_digit, s_rank, s_cnt_le;
+    __shared__ uint32_t s_digit, s_rank, s_cnt_le, s_wave[4];
     __shared__ unsigned long long s_min_gt;
     const uint32_t s = blockIdx.x;
     const int tid = threadIdx.x;
@@ -807,7 +826,20 @@ __global__ __launch_bounds__(256) void tune_final_kernel(const SongDesc* __restr
     // (e.g. click tracks: a flat spectrum) in a chunk whose pool is already full.
     auto for_each = [&](auto&& fn) {
         if (pooled) {
-            for (uint32_t i = tid; i < nc; i += 256) fn(v[i], (int)pb[i]);
+            // eight candidates requested per trip: one at a time, every pass of the select paid the L2 latency nc / 256 times
+            for (uint32_t i0 = tid; i0 < nc; i0 += 8 * 256) {
+                double m8[8];
+                int b8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t i = i0 + 256u * u;
+                    m8[u] = i < nc ? v[i] : 0.0;
+                    b8[u] = i < nc ? (int)pb[i] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (i0 + 256u * u < nc) fn(m8[u], b8[u]);
+            }
         } else {
             for (uint32_t f = 0; f < sd.n_c; f++) {
                 const uint32_t n_rec = peak_cnt[sd.c_off + f];
@@ -825,7 +857,7 @@ __global__ __launch_bounds__(256) void tune_final_kernel(const SongDesc* __restr
         }
     };
 
-    const uint64_t key_lo = block_radix_select(for_each, k_lo, hist, &s_digit, &s_rank);
+    const uint64_t key_lo = block_radix_select(for_each, k_lo, hist, &s_digit, &s_rank, s_wave);
     uint64_t key_hi = key_lo;
     if (k_hi != k_lo) {
         // the next order statistic: key_lo again if it is repeated, else the smallest key above it
