@@ -468,6 +468,11 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
             __syncthreads();
         }
         const uint32_t lbase = lhist_base;
+        // The peak phase is a chain of LDS round trips with little arithmetic between them, the transform passes are long
+        // runs of arithmetic: a wavefront in the peak phase gets the issue slot first, so its few instructions never queue
+        // behind another workgroup's radix pass (FFT-8192 kernel -1.9 %; raising the priority of the exchange / split
+        // phases as well, or lowering it inside the radix passes only, is slower than no priorities at all).
+        __builtin_amdgcn_s_setprio(2);
         // ---- pip_track pass 1: count peaks by coarse magnitude bin.  Every lane tests its six bins; the peaks (about a
         // third of the bins) are compacted through an LDS list so the interpolation arithmetic runs on dense
         // wavefronts instead of six times under a one-third-full exec mask ----
@@ -520,6 +525,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
                 else atomicAdd(&hist[b], 1u);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (has_next) {
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window of the next frame

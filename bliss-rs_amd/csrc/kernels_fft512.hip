@@ -123,18 +123,25 @@ struct RegTables {
 template <int R>
 __device__ __forceinline__ void fft512_compute(f2 (&raw)[16], int l, f2* tile, const RegTables& tabs, FrameMags& out) {
     f2 v[16];
+    // Issue priority: low inside the two radix passes (long runs of arithmetic), high for everything else in the frame
+    // -- the LDS exchanges, the split reads, the timbral epilogue and the PCM statistics are short bursts between waits,
+    // and a wavefront in one of them should not queue behind the other wavefront's radix pass (FFT-512 kernel -2.5 %)
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int n1 = 0; n1 < 16; n1++) v[n1] = row<R>(raw, n1) * tabs.win[n1];
     radix16(v);  // over n1 -> A[k1] at v[R16(k1)]
 #pragma unroll
     for (int k1 = 1; k1 < 16; k1++) v[R16(k1)] = cmul_pk(v[R16(k1)], tabs.tw256[k1]);  // W_256^(l*k1)
+    __builtin_amdgcn_s_setprio(2);
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) tile[k1 * 17 + l] = v[R16(k1)];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int n2 = 0; n2 < 16; n2++) v[n2] = tile[l * 17 + n2];
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_setprio(0);
     radix16(v);  // over n2 -> Z[l + 16 k2] at v[R16(k2)]
+    __builtin_amdgcn_s_setprio(2);
 #pragma unroll
     for (int k2 = 0; k2 < 16; k2++) tile[k2 * 17 + l] = v[R16(k2)];  // Z[k] at k + (k >> 4)
     __builtin_amdgcn_wave_barrier();
