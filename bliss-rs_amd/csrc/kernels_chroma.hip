@@ -170,12 +170,17 @@ __device__ __forceinline__ uint32_t peak_coarse_bin(float sb, float se, float sa
 }
 
 // pitch-residue bin in f32, or -1 when it is not provably the f64 pitch_bin(): the peak must not be flat
-// (den >= 2^-10 se bounds the shift error by 1e-4, i.e. 3e-3 bins at c >= 57) and the bin coordinate must
-// be at least 0.02 away from an integer (v_log_f32 + f32 rounding stay below 3e-3 bins).
+// (den >= 2^-8 se bounds the shift error by 2.8e-5 FFT bins, i.e. 8.5e-4 tuning bins at c >= 57) and the bin
+// coordinate must be at least PITCH_GUARD away from an integer (v_log_f32 at 1 ulp of a result below 16, the constant
+// add, the x12 and the rounding of c + shift stay below 1.9e-3 bins: 2.8e-3 in all).  Checked against the f64 path on
+// 2e9 random peaks from sharp to flat (tests/tools/probes/guard_probe.hip): no disagreement down to a guard of 0.002,
+// the first ones at 0.001.  The records whose bin is not provable take tune_pass2_kernel's f64 path -- 1.6 % of the
+// peaks with this guard; with 0.02 / 2^-10 it was 4 % and that path is two thirds of that kernel's time.
+constexpr float PITCH_GUARD = 0.008f, PITCH_FLAT_LIMIT = 0.00390625f;
 __device__ __forceinline__ int peak_pitch_bin_f32(float sb, float se, float sa, int c) {
     const float avg = 0.5f * (sa - sb);
     const float den = (2.0f * se - sa) - sb;
-    if (!(se >= 1e-30f) || den < se * 0.0009765625f) return -1;
+    if (!(se >= 1e-30f) || den < se * PITCH_FLAT_LIMIT) return -1;
     const float shift = avg * __builtin_amdgcn_rcpf(den);
     // 12 log2(pitch / 27.5) with pitch = (c + shift) * 22050 / 8192
     float x = 12.0f * (__builtin_amdgcn_logf((float)c + shift) + -3.3528687f);  // log2(22050 / 8192 / 27.5)
@@ -183,7 +188,7 @@ __device__ __forceinline__ int peak_pitch_bin_f32(float sb, float se, float sa, 
     if (x >= 0.5f) x -= 1.0f;
     const float q = (x + 0.5f) * 100.0f;
     const float fl = floorf(q), fr = q - fl;
-    if (fr < 0.02f || fr > 0.98f) return -1;
+    if (fr < PITCH_GUARD || fr > 1.0f - PITCH_GUARD) return -1;
     const int idx = (int)fl;
     return idx < 0 ? 0 : (idx > N_TUNING - 1 ? N_TUNING - 1 : idx);
 }
@@ -205,13 +210,13 @@ __device__ __forceinline__ uint32_t peak_classify(float sb, float se, float sa, 
     const bool normal = se >= 1e-30f;
     // pitch bin
     int pb = -1;
-    if (normal && !(den < se * 0.0009765625f)) {
+    if (normal && !(den < se * PITCH_FLAT_LIMIT)) {
         float x = 12.0f * (__builtin_amdgcn_logf((float)c + shift) + -3.3528687f);
         x = x - truncf(x);
         if (x >= 0.5f) x -= 1.0f;
         const float q = (x + 0.5f) * 100.0f;
         const float fl = floorf(q), fr = q - fl;
-        if (!(fr < 0.02f || fr > 0.98f)) {
+        if (!(fr < PITCH_GUARD || fr > 1.0f - PITCH_GUARD)) {
             const int idx = (int)fl;
             pb = idx < 0 ? 0 : (idx > N_TUNING - 1 ? N_TUNING - 1 : idx);
         }
