@@ -196,6 +196,25 @@ def test_coalesced_batch_with_mixed_input_classes(bliss, oracle):
         assert got[i].shape == want[i % 4].shape and np.array_equal(got[i], want[i % 4])
 
 
+def test_f32_peak_classifier_agrees_with_the_f64_path(tmp_path):
+    """The FFT-8192 kernel files a peak under a pitch bin from an f32 evaluation unless the bin coordinate lies inside a
+    guard band around a bin edge (then tuning pass 2 redoes it in f64, the reference's arithmetic).  The probe classifies
+    2e8 random peaks, sharp to flat, with the production function and with narrower bands: the production setting must
+    never disagree with the f64 path, and neither may a band four times narrower (the margin)."""
+    src = os.path.join(ROOT, "tests", "tools", "probes", "guard_probe.hip")
+    exe = str(tmp_path / "guard_probe")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result",
+                    "-I", os.path.join(ROOT, "bliss-rs_amd", "csrc"), "-I", os.path.join(ROOT, "include"), "-o", exe, src],
+                   check=True, timeout=600)
+    out = subprocess.run([exe, "200"], check=True, capture_output=True, text=True, timeout=300).stdout
+    rows = [l for l in out.splitlines() if "f32 bins differ" in l]
+    assert rows and rows[0].startswith("production")
+    bad = {float(l.split("guard")[1].split(",")[0]): int(l.split("f64 path,")[1].split()[0]) for l in rows}
+    assert int(rows[0].split("f64 path,")[1].split()[0]) == 0, out
+    assert bad[0.002] == 0, out          # four times narrower than the production band: still exact
+    assert bad[0.0005] > 0, out          # and the probe does find disagreements once the band is too narrow
+
+
 def test_two_contexts_run_concurrently_from_two_threads(bliss, oracle):
     songs = [oracle.white_noise(700 + i, 6 * 22050 + 1000 * i) for i in range(6)]
     ref, _ = _run(bliss.Context(0), songs)

@@ -6,6 +6,7 @@
 // build (from the repo root): hipcc --offload-arch=gfx950 -O3 -std=c++17 -I bliss-rs_amd/csrc -I include -o tests/tools/probes/guard_probe tests/tools/probes/guard_probe.hip
 #include "kernels_chroma.hip"
 #include <stdio.h>
+#include <stdlib.h>
 using namespace bg;
 __device__ __forceinline__ uint32_t rng(uint64_t& s) { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(s >> 33); }
 __device__ __forceinline__ int pitch_bin_f32_guard(float sb, float se, float sa, int c, float guard, float flat_limit) {
@@ -22,9 +23,9 @@ __device__ __forceinline__ int pitch_bin_f32_guard(float sb, float se, float sa,
     const int idx = (int)fl;
     return idx < 0 ? 0 : (idx > N_TUNING - 1 ? N_TUNING - 1 : idx);
 }
-constexpr int NG = 6;
-__constant__ float GUARD[NG] = {0.02f, 0.008f, 0.004f, 0.002f, 0.001f, 0.0005f};
-__constant__ float FLAT[NG] = {1.0f / 1024, 1.0f / 256, 1.0f / 256, 1.0f / 256, 1.0f / 256, 1.0f / 256};
+constexpr int NG = 6;  // setting 0 = the production classifier itself (peak_pitch_bin_f32 with PITCH_GUARD / PITCH_FLAT_LIMIT)
+__constant__ float GUARD[NG] = {PITCH_GUARD, 0.02f, 0.004f, 0.002f, 0.001f, 0.0005f};
+__constant__ float FLAT[NG] = {PITCH_FLAT_LIMIT, 1.0f / 1024, 1.0f / 256, 1.0f / 256, 1.0f / 256, 1.0f / 256};
 __global__ void probe(unsigned long long* slow, unsigned long long* bad, int iters, uint64_t seed) {
     uint64_t s = seed + 0x9E3779B97F4A7C15ull * (blockIdx.x * 256 + threadIdx.x + 1);
     unsigned long long lslow[NG] = {}, lbad[NG] = {};
@@ -46,25 +47,25 @@ __global__ void probe(unsigned long long* slow, unsigned long long* bad, int ite
         const int exact = pitch_bin(pitch);
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            const int pb = pitch_bin_f32_guard(sb, se, sa, c, GUARD[g], FLAT[g]);
+            const int pb = g == 0 ? peak_pitch_bin_f32(sb, se, sa, c) : pitch_bin_f32_guard(sb, se, sa, c, GUARD[g], FLAT[g]);
             if (pb < 0) lslow[g]++;
             else if (pb != exact) lbad[g]++;
         }
     }
     for (int g = 0; g < NG; g++) { atomicAdd(&slow[g], lslow[g]); atomicAdd(&bad[g], lbad[g]); }
 }
-int main() {
+int main(int argc, char** argv) {
     unsigned long long *slow, *bad, hs[NG], hb[NG];
     (void)hipMalloc(&slow, NG * 8); (void)hipMalloc(&bad, NG * 8);
     (void)hipMemset(slow, 0, NG * 8); (void)hipMemset(bad, 0, NG * 8);
-    const int blocks = 4096, iters = 2000;
+    const int blocks = 4096, iters = argc > 1 ? atoi(argv[1]) : 2000;
     hipLaunchKernelGGL(probe, dim3(blocks), dim3(256), 0, 0, slow, bad, iters, 12345ull);
     (void)hipMemcpy(hs, slow, NG * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(hb, bad, NG * 8, hipMemcpyDeviceToHost);
     const double total = (double)blocks * 256 * iters;
-    const float G[NG] = {0.02f, 0.008f, 0.004f, 0.002f, 0.001f, 0.0005f};
-    const int F[NG] = {1024, 256, 256, 256, 256, 256};
+    const float G[NG] = {PITCH_GUARD, 0.02f, 0.004f, 0.002f, 0.001f, 0.0005f};
+    const float F[NG] = {PITCH_FLAT_LIMIT, 1.0f / 1024, 1.0f / 256, 1.0f / 256, 1.0f / 256, 1.0f / 256};
     for (int g = 0; g < NG; g++)
-        printf("guard %.4f, den >= se / %4d: %.2f %% of ~%.1e peaks to the f64 path, %llu f32 bins differ from the f64 bin\n", G[g], F[g],
-               100.0 * hs[g] / total, total, hb[g]);
+        printf("%s guard %.4f, den >= se / %4.0f: %.2f %% of ~%.1e peaks to the f64 path, %llu f32 bins differ from the f64 bin\n",
+               g == 0 ? "production" : "variant   ", G[g], 1.0 / F[g], 100.0 * hs[g] / total, total, hb[g]);
     return 0;
 }
