@@ -1035,10 +1035,13 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
             "ds_read_b128 %5, %6 offset:2304\n\t"
             "s_waitcnt lgkmcnt(0)"
             : "=&v"(as.a[0][0]), "=&v"(as.a[0][1]), "=&v"(as.a[1][0]), "=&v"(as.a[1][1]), "=&v"(as.a[2][0]), "=&v"(as.a[2][1])
-            : "v"(addr));
+            : "v"(addr)
+            : "memory");
     };
     // The spectrogram loads are asm statements too, so that NO wait in the loop is the compiler's: with global->LDS
-    // transfers in the queue its counter tracking falls back to vmcnt(0) for ordinary loads as well.
+    // transfers in the queue its counter tracking falls back to vmcnt(0) for ordinary loads as well.  Every asm statement
+    // of the loop clobbers "memory": the hand-counted vmcnt values rely on the program order of these statements AND of
+    // the DMA intrinsics between them.
     auto b_load = [&](int blk, BBlock& bb) {
         const int k0 = 32 * (blk < KBLOCKS ? blk : KBLOCKS - 1);
 #pragma unroll
@@ -1046,7 +1049,8 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
             const float* p = brow[q] + k0;
             asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
                          : "=&v"(bb.b[0][q]), "=&v"(bb.b[1][q])
-                         : "v"(p));
+                         : "v"(p)
+                         : "memory");
         }
     };
     // Everything issued before the spectrogram block B(j+1) has landed: in program order that is A(j) [3 transfers],
@@ -1055,7 +1059,9 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
     auto wait_block = [&](BBlock& bb) {
         asm volatile("s_waitcnt vmcnt(8)"
                      : "+v"(bb.b[0][0]), "+v"(bb.b[0][1]), "+v"(bb.b[0][2]), "+v"(bb.b[0][3]), "+v"(bb.b[1][0]),
-                       "+v"(bb.b[1][1]), "+v"(bb.b[1][2]), "+v"(bb.b[1][3]));
+                       "+v"(bb.b[1][1]), "+v"(bb.b[1][2]), "+v"(bb.b[1][3])
+                     :
+                     : "memory");
     };
     auto step_mma = [&](const AStep& as, const BBlock& bb, int u) {
 #pragma unroll
