@@ -146,6 +146,72 @@ def test_battery_vs_oracle(ctx, oracle, version):
     assert len(tempo_mismatch) == EXPECTED_TEMPO_MISMATCHES, tempo_mismatch
 
 
+def musical_battery(oracle):
+    """Signals with structure in the places the white-noise bench has none: detuned harmony (the tuning estimate must
+    land in another bin and select another filter bank), steady and swung pulses (the beat tracker's lock), modulated
+    and harmonic tones, a 10-minute song (the longest the mixed corpus holds), amplitudes far from 1."""
+    sr = 22050
+    rng = np.random.default_rng(99)
+
+    def chord(freqs, seconds, cents=0.0, amp=0.2):
+        t = np.arange(int(seconds * sr)) / sr
+        k = 2.0 ** (cents / 1200.0)
+        return (sum(np.sin(2 * np.pi * f * k * t) for f in freqs) * amp).astype(np.float32)
+
+    def bursts(period_s, seconds, width_s=0.05, swing=0.0):
+        x = np.zeros(int(seconds * sr), np.float32)
+        noise = rng.standard_normal(len(x)).astype(np.float32) * 0.5
+        k, t0 = 0, 0.0
+        while t0 < seconds - width_s:
+            a = int(t0 * sr)
+            b = a + int(width_s * sr)
+            x[a:b] = noise[a:b] * np.hanning(b - a).astype(np.float32)
+            k += 1
+            t0 = k * period_s + (swing * period_s if k % 2 else 0.0)
+        return x
+
+    t15 = np.arange(15 * sr) / sr
+    saw = (2.0 * ((110.0 * t15) % 1.0) - 1.0).astype(np.float32) * 0.4
+    am = (np.sin(2 * np.pi * 440.0 * t15) * (0.5 + 0.5 * np.sin(2 * np.pi * 2.0 * t15))).astype(np.float32) * 0.6
+    return {
+        "chord_plus_23_cents": chord((220.0, 277.18, 329.63, 440.0), 25, cents=23.0),
+        "chord_minus_41_cents": chord((196.0, 246.94, 293.66), 25, cents=-41.0),
+        "chord_over_noise": chord((261.63, 329.63, 392.0), 30, cents=8.0) + oracle.white_noise(31, 30 * sr) * 0.05,
+        "bursts_120bpm": bursts(0.5, 40),
+        "bursts_93bpm_swing": bursts(60.0 / 93.0, 45, swing=0.17),
+        "bursts_172bpm": bursts(60.0 / 172.0, 35, width_s=0.02),
+        "am_tone_440": am,
+        "sawtooth_110": saw,
+        "noise_10min": oracle.white_noise(32, 10 * 60 * sr),
+        "tiny_amplitude_1e-12": oracle.white_noise(33, 12 * sr) * np.float32(1e-12),
+        "huge_amplitude_1e4": oracle.white_noise(34, 9 * sr) * np.float32(1e4),
+    }
+
+
+def test_musical_battery_vs_oracle(ctx, oracle):
+    songs = musical_battery(oracle)
+    names = list(songs)
+    got, status = _run(ctx, [songs[k] for k in names], 2)
+    tuning, n_bpms = ctx.last_tuning(len(names))
+    assert (status == 0).all()
+    tempo_mismatch, report, tunings = [], [], set()
+    for i, k in enumerate(names):
+        ref = oracle.song_analyze(songs[k], 2)
+        _, otuning = oracle.chroma_desc(songs[k])
+        err = np.abs(got[i] - ref)
+        tol = _tol(len(songs[k]), len(ref))
+        report.append(f"{k:26s} max|err| non-tempo {err[1:].max():.2e} tempo {err[0]:.2e} tuning {tuning[i]:+.2f}/{otuning:+.2f} bpms {n_bpms[i]}")
+        assert abs(tuning[i] - otuning) < 1e-12, f"{k}: tuning gpu {tuning[i]} oracle {otuning}"
+        assert (err[1:] <= tol[1:]).all(), f"{k}: {err}"
+        if err[0] > tol[0]:
+            tempo_mismatch.append((k, float(got[i][0]), float(ref[0])))
+        tunings.add(round(float(tuning[i]), 2))
+    print("\n".join(report))
+    print("tempo mismatches:", tempo_mismatch)
+    assert len(tunings) >= 4, tunings            # the battery does exercise several filter banks
+    assert len(tempo_mismatch) == EXPECTED_TEMPO_MISMATCHES, tempo_mismatch
+
+
 def test_stage_taps_vs_oracle(ctx, oracle, golden_pcm):
     """Every intermediate series against the oracle's streaming descriptors."""
     songs = [golden_pcm, oracle.white_noise(21, 30 * 22050 + 100)]
