@@ -215,6 +215,27 @@ def test_f32_peak_classifier_agrees_with_the_f64_path(tmp_path):
     assert bad[0.0005] > 0, out          # and the probe does find disagreements once the band is too narrow
 
 
+@pytest.mark.timeout(120)
+def test_non_finite_samples_stay_inside_their_song(bliss, oracle):
+    """A song with NaN / Inf samples must not hang the batch nor leak into its neighbours (shared histogram windows,
+    candidate pool, per-chunk series): the other rows are bit-identical to their solo analysis, the poisoned rows are
+    reported as analysed (the reference returns whatever the arithmetic yields; it does not reject such input)."""
+    a = oracle.white_noise(71, 9 * 22050)
+    b = oracle.white_noise(72, 14 * 22050 + 5)
+    nan_song = oracle.white_noise(73, 11 * 22050).copy()
+    nan_song[50000] = np.nan
+    inf_song = oracle.white_noise(74, 10 * 22050).copy()
+    inf_song[1234] = np.inf
+    inf_song[99999] = -np.inf
+    solo_a = bliss.Song.analyze(a).as_arr1()
+    solo_b = bliss.Song.analyze(b).as_arr1()
+    rows = bliss.analyze_batch([a, nan_song, b, inf_song])
+    assert np.array_equal(rows[0].as_arr1(), solo_a)
+    assert np.array_equal(rows[2].as_arr1(), solo_b)
+    assert not np.isfinite(rows[1].as_arr1()).all()
+    assert not np.isfinite(rows[3].as_arr1()).all()
+
+
 def test_two_contexts_run_concurrently_from_two_threads(bliss, oracle):
     songs = [oracle.white_noise(700 + i, 6 * 22050 + 1000 * i) for i in range(6)]
     ref, _ = _run(bliss.Context(0), songs)
