@@ -144,29 +144,33 @@ static_assert(BT_PRE_STRIDE >= 260, "per-run record");
 
 typedef float bt_f2 __attribute__((ext_vector_type(2)));
 
-// acc += f[i] * (w[i], w[i + 1]) for 16 consecutive i: the lag pair (L, L + 1) of one thread, w = frame + L.  w1 is the
-// same series one element on (a second copy in LDS), so that the odd steps' operand pairs (w[i], w[i + 1]) also arrive in
-// even-aligned register pairs: gfx950 takes 64-bit operands from aligned pairs only, and a copy per step costs more than
-// the LDS read.
+// acc01 += f[i] * (w[i], w[i+1]), acc23 += f[i] * (w[i+2], w[i+3]) for 16 consecutive i: the four lags (L .. L + 3) of
+// one thread, w = frame + L.  The packed multiply / add takes two lags per instruction; w1 is the same series one element
+// on (a second copy in LDS), so that the odd steps' operand pairs also arrive in even-aligned register pairs (gfx950 takes
+// 64-bit operands from aligned pairs only, and a copy per step costs more than the LDS read).  Four lags per thread
+// instead of two halve the LDS bytes per multiply-add: 18 + 18 values feed 64 of them.
 template <typename F>
-__device__ __forceinline__ void acf_block16(bt_f2& acc, const float* w, const float* w1, F&& f_at) {
-    float r[16], r1[16];
+__device__ __forceinline__ void acf_block16(bt_f2& acc01, bt_f2& acc23, const float* w, const float* w1, F&& f_at) {
+    float r[18], r1[18];
 #pragma unroll
-    for (int u = 0; u < 16; u++) { r[u] = w[u]; r1[u] = w1[u]; }
+    for (int u = 0; u < 18; u++) { r[u] = w[u]; r1[u] = w1[u]; }
 #pragma unroll
     for (int u = 0; u < 16; u += 2) {
         const float f0 = f_at(u), f1 = f_at(u + 1);
-        const bt_f2 w_even = {r[u], r[u + 1]}, w_odd = {r1[u], r1[u + 1]};
         const bt_f2 fv0 = {f0, f0}, fv1 = {f1, f1};
-        acc = acc + fv0 * w_even;
-        acc = acc + fv1 * w_odd;
+        const bt_f2 e01 = {r[u], r[u + 1]}, e23 = {r[u + 2], r[u + 3]};      // step u:     w[u .. u+3]
+        const bt_f2 o01 = {r1[u], r1[u + 1]}, o23 = {r1[u + 2], r1[u + 3]};  // step u + 1: w[u+1 .. u+4]
+        acc01 = acc01 + fv0 * e01;
+        acc23 = acc23 + fv0 * e23;
+        acc01 = acc01 + fv1 * o01;
+        acc23 = acc23 + fv1 * o23;
     }
 }
 
-__global__ __launch_bounds__(128) void beat_acf_kernel(const SongDesc* __restrict__ songs,
-                                                       const float* __restrict__ thresholded,
-                                                       const float* __restrict__ rwv_tab,
-                                                       float* __restrict__ pre_all) {
+__global__ __launch_bounds__(64) void beat_acf_kernel(const SongDesc* __restrict__ songs,
+                                                      const float* __restrict__ thresholded,
+                                                      const float* __restrict__ rwv_tab,
+                                                      float* __restrict__ pre_all) {
     __shared__ float df[2 * BT_WINLEN];  // [512, 1024) stays zero: the ACF loops read past the frame instead of predicating
     __shared__ float df1[2 * BT_WINLEN];  // df1[j] = df[j + 1]
     __shared__ float acf[BT_WINLEN];
@@ -178,22 +182,22 @@ __global__ __launch_bounds__(128) void beat_acf_kernel(const SongDesc* __restric
     const long n_b = sd.n_b;
     const long n_runs = (n_b >= BT_STEP) ? (n_b - BT_STEP) / BT_STEP + 1 : 0;
     if (m >= n_runs) return;
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x;  // one wavefront per run
     const float* thr = thresholded + sd.b_off;
     float* pre = pre_all + ((size_t)(sd.b_off / BT_STEP) + s + (size_t)m) * BT_PRE_STRIDE;
 
     // ---- dfframe for run m: s[128(m+1)-512+i], s[x] = 0 for x <= 0, thr[x-1] otherwise (Tempo::do_ :1389-1416) ----
     {
-        float v[4];
+        float v[8];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {  // all four loads in flight together; the address is clamped instead of branching
-            const long xi = 128 * (m + 1) - 512 + tid + 128 * q;
+        for (int q = 0; q < 8; q++) {  // all eight loads in flight together; the address is clamped instead of branching
+            const long xi = 128 * (m + 1) - 512 + tid + 64 * q;
             const float x = thr[xi > 0 ? xi - 1 : 0];
             v[q] = (xi <= 0) ? 0.0f : x;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = tid + 128 * q;
+        for (int q = 0; q < 8; q++) {
+            const int i = tid + 64 * q;
             df[i] = v[q];
             if (i > 0) df1[i - 1] = v[q];
             df[BT_WINLEN + i] = 0.0f;
@@ -202,46 +206,50 @@ __global__ __launch_bounds__(128) void beat_acf_kernel(const SongDesc* __restric
     }
     __syncthreads();
     // vec_autocorr (:819-828): acf[L] = (sum_{j=L}^{511} f[j-L] f[j]) / (512 - L), summed in j order.  A thread owns
-    // the lag pairs (2t, 2t+1) and (510-2t, 511-2t) -- a long and a short pair, so both wavefronts do the same work --
-    // and runs i = j - L over the two lags of a pair at once (packed multiply, packed add).  The first factor f[i] is
-    // wave-uniform, so for runs whose frame lies inside the song it comes from SCALAR loads of the thresholded series:
-    // the kernel is bound by LDS bandwidth (two dwords per lane and step for the pair), and a broadcast LDS read of
-    // f[i] would add half as much again (measured: 1.69 vs 1.46 ms per 1024 songs).  The loops run to the wave-uniform bound 512 - (smallest lag of the wave) and read the zero padding
-    // behind the frame instead of predicating (x + f * 0 == x exactly, so every sum is bit-identical to the
-    // reference's).
+    // the lag quads (4t .. 4t+3) and (508-4t .. 511-4t) -- a long and a short one -- and runs i = j - L over the four
+    // lags of a quad at once (packed multiply, packed add: two lags per instruction).  The first factor f[i] is
+    // wave-uniform, so for runs whose frame lies inside the song it comes from SCALAR loads of the thresholded series
+    // (the kernel is bound by LDS bandwidth; a broadcast LDS read of f[i] would add to it).  The loops run to the
+    // wave-uniform bounds 512 and 256 (the smallest lag of each kind is 0 and 256) and read the zero padding behind the
+    // frame instead of predicating (x + f * 0 == x exactly, so every sum is bit-identical to the reference's).
     {
-        const int la = 2 * tid, lb = BT_WINLEN - 2 - 2 * tid;
-        const int na = BT_WINLEN - 128 * wave, nb = 128 + 128 * wave;
-        bt_f2 acc_a = {0.0f, 0.0f}, acc_b = {0.0f, 0.0f};
+        const int la = 4 * tid, lb = BT_WINLEN - 4 - 4 * tid;
+        constexpr int na = BT_WINLEN, nb = BT_WINLEN / 2;
+        bt_f2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f}, b01 = {0.0f, 0.0f}, b23 = {0.0f, 0.0f};
         if (m >= 4) {
             const float* __restrict__ fs = thr + (128 * (m + 1) - 512) - 1;  // fs[i] == dfframe[i], wave-uniform
             for (int i = 0; i < na; i += 16) {
                 float sv[16];
 #pragma unroll
                 for (int u = 0; u < 16; u++) sv[u] = fs[i + u];
-                acf_block16(acc_a, df + la + i, df1 + la + i, [&](int u) { return sv[u]; });
+                acf_block16(a01, a23, df + la + i, df1 + la + i, [&](int u) { return sv[u]; });
             }
             for (int i = 0; i < nb; i += 16) {
                 float sv[16];
 #pragma unroll
                 for (int u = 0; u < 16; u++) sv[u] = fs[i + u];
-                acf_block16(acc_b, df + lb + i, df1 + lb + i, [&](int u) { return sv[u]; });
+                acf_block16(b01, b23, df + lb + i, df1 + lb + i, [&](int u) { return sv[u]; });
             }
         } else {
-            for (int i = 0; i < na; i += 16) acf_block16(acc_a, df + la + i, df1 + la + i, [&](int u) { return df[i + u]; });
-            for (int i = 0; i < nb; i += 16) acf_block16(acc_b, df + lb + i, df1 + lb + i, [&](int u) { return df[i + u]; });
+            for (int i = 0; i < na; i += 16) acf_block16(a01, a23, df + la + i, df1 + la + i, [&](int u) { return df[i + u]; });
+            for (int i = 0; i < nb; i += 16) acf_block16(b01, b23, df + lb + i, df1 + lb + i, [&](int u) { return df[i + u]; });
         }
-        acf[la] = acc_a.x / (float)(BT_WINLEN - la);
-        acf[la + 1] = acc_a.y / (float)(BT_WINLEN - la - 1);
-        acf[lb] = acc_b.x / (float)(BT_WINLEN - lb);
-        acf[lb + 1] = acc_b.y / (float)(BT_WINLEN - lb - 1);
+        acf[la] = a01.x / (float)(BT_WINLEN - la);
+        acf[la + 1] = a01.y / (float)(BT_WINLEN - la - 1);
+        acf[la + 2] = a23.x / (float)(BT_WINLEN - la - 2);
+        acf[la + 3] = a23.y / (float)(BT_WINLEN - la - 3);
+        acf[lb] = b01.x / (float)(BT_WINLEN - lb);
+        acf[lb + 1] = b01.y / (float)(BT_WINLEN - lb - 1);
+        acf[lb + 2] = b23.x / (float)(BT_WINLEN - lb - 2);
+        acf[lb + 3] = b23.y / (float)(BT_WINLEN - lb - 3);
     }
     __syncthreads();
     // shift-invariant comb filterbank (:987-1003): the sums run a = 1 .. numelem in order, so the numelem = 4 value is
     // the numelem = 3 value continued.  Rayleigh path: terms divided by 2a - 1, weighted by rwv; the unweighted sums
     // are what checkstate weights by its Gaussian (:1110-1124).
-    {
-        const int l = tid;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int l = tid + 64 * half;
         float v3 = 0.0f, v4 = 0.0f, g3 = 0.0f, g4 = 0.0f;
         if (l >= 1 && l < BT_LAGLEN - 1) {
             float v = 0.0f, g = 0.0f;
@@ -264,18 +272,18 @@ __global__ __launch_bounds__(128) void beat_acf_kernel(const SongDesc* __restric
         pre[BT_PRE_G4 + l] = g4;
     }
     __syncthreads();
-    {
-        const int lane = tid & 63;
-        const float x[2] = {acfout[wave][lane], acfout[wave][lane + 64]};
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+        const float x[2] = {acfout[which][tid], acfout[which][tid + 64]};
         float best;
         int maxindex;
         wave_argmax_last(x, &best, &maxindex);
-        if (lane == 0) {
+        if (tid == 0) {
             const int rayparam = 43;  // (60*22050/120/256) as u32
-            const float rp = (maxindex > 0 && maxindex < BT_LAGLEN - 1) ? quad_peak_pos(acfout[wave], BT_LAGLEN, maxindex)
+            const float rp = (maxindex > 0 && maxindex < BT_LAGLEN - 1) ? quad_peak_pos(acfout[which], BT_LAGLEN, maxindex)
                                                                        : (float)rayparam;
-            pre[BT_PRE_RP3 + wave] = rp;
-            pre[BT_PRE_TS3 + wave] = bt_timesig(acf, (long)rp);
+            pre[BT_PRE_RP3 + which] = rp;
+            pre[BT_PRE_TS3 + which] = bt_timesig(acf, (long)rp);
         }
     }
 }
@@ -534,7 +542,7 @@ void launch_beat(const Batch& b, const Workspace& w, const DeviceTables& t, hipS
     if (b.n_songs == 0) return;
     const uint32_t max_runs = b.max_nb >= (uint32_t)BT_STEP ? (b.max_nb - BT_STEP) / BT_STEP + 1 : 0;
     if (max_runs > 0)
-        hipLaunchKernelGGL(beat_acf_kernel, dim3(max_runs, b.n_songs), dim3(128), 0, st, b.songs, w.thresholded, t.bt_rwv,
+        hipLaunchKernelGGL(beat_acf_kernel, dim3(max_runs, b.n_songs), dim3(64), 0, st, b.songs, w.thresholded, t.bt_rwv,
                            w.bt_pre);
     hipLaunchKernelGGL(beat_track_kernel, dim3(b.n_songs), dim3(64), 0, st, b.songs, w.thresholded, w.e256, t.bt_dfwv,
                        w.bt_pre, w.run_bpm, w.run_cnt, w.runs_pitch, w.tempo);
