@@ -26,8 +26,6 @@
 namespace bg {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef double double2_t __attribute__((ext_vector_type(2)));
-typedef float float4_t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // chroma filter bank
@@ -331,6 +329,11 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
     uint32_t* hist = h1 + (size_t)s * H1_BINS;
     for (int i = t; i < LHIST_BINS; i += 256) lhist[i] = 0;
     bool have_base = false;
+    // tw256 is read across wavefronts by the first frame's pass 1.  Without this barrier a wavefront that got ahead read
+    // whatever the previous workgroup left in the LDS -- the same table, unless that was another kernel's data: about one
+    // frame in 10^8 was transformed with stale twiddles (a chroma row off by 1e-6 .. 4e-3 once in some 10^4 songs, found
+    // by tests/tools/determinism_check.py; every parity test passed).
+    __syncthreads();
 
     // raw samples of one frame: z[256*n1 + t] = (x[w0 + 2n], x[w0 + 2n + 1]), reflect only at the song edges
     auto load_frame = [&](uint32_t f, f2 (&xr)[16]) {
@@ -951,14 +954,7 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
                                                      const double* __restrict__ bank,
                                                      const TuningState* __restrict__ tuning,
                                                      double* __restrict__ chroma_part) {
-    // one object so that the order is fixed: the DMA ring lies in the first 64 KB of the workgroup's LDS
-    __shared__ struct {
-        double2_t a_ring[4][3][3][64];  // [wavefront][ring slot][row group][DMA lane]: 16 bytes each
-        double tile_c[4][4][16][13];
-    } sm;
-    auto& a_ring = sm.a_ring;
-    auto& tile_c = sm.tile_c;
-    static_assert(sizeof(sm.a_ring) <= 65536, "DMA targets within the first 64 KB");
+    __shared__ double tile_c[4][4][16][13];
     const uint32_t s = find_segment(pfx_cw, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
     const int lane = lane_id(), wave = wave_id();
@@ -970,19 +966,13 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
     const int slot = (tidx < 0) ? N_TUNING : tidx;
     const uint32_t f0 = tile64 * CH_TILE;
 
-    // The contraction runs on v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 blocks per instruction.  A block is a
-    // group of four frames, every block takes the SAME four filter rows, and three instructions (rows 0-3, 4-7, 8-11)
-    // cover the 12 chroma classes exactly -- the 16x16x4 form spends a quarter of its rows on padding and, on this
-    // chip, runs at 60 instead of 77 TFLOP/s (tests/tools/probes/mfma_probe.hip: 4.1 vs 2.4 ms for this kernel's work).
-    // Operand layout (tests/tools/probes/mfma_layout.hip): lane = x + 4 blk + 16 y with A: x = row, y = k;
-    // B: x = frame within the block, y = k; D: x = frame, y = row.  So lane % 16 is the frame of a 16-frame sub-tile
-    // and lane / 16 the k slot, exactly as in the 16x16x4 form, and a lane's filter rows are (lane % 4) + {0, 4, 8}.
-    //
     // K is consumed in an order chosen for the memory system, not 0, 1, 2, ...: within a 32-bin (128-byte) block the four
     // lanes of a frame sit 32 bytes apart and take two 16-byte pieces each, so EVERY load instruction touches both
     // 64-byte halves of its 16 lines.  With the natural order (lane g on bins 4g..4g+3: 64 contiguous bytes per frame and
     // instruction) the same bytes arrive at 4.7 TB/s instead of 5.9 (tests/tools/probes/bw_probe.hip).  The filter (A)
-    // fragments follow the same permutation, so the sum over K has the same terms.
+    // fragments follow the same permutation, so the sum over K has the same terms.  (Filter rows 12..15 of the 16-row MFMA
+    // tile do not exist: those lanes re-read row 11 and their results are never stored.)
+    const double* __restrict__ arow = bank + ((size_t)slot * BANK_ROWS + (i16 < BANK_ROWS ? i16 : BANK_ROWS - 1)) * BANK_PITCH + 8 * g;
     const float* brow[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -990,126 +980,68 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
         if (fj >= sd.n_c) fj = sd.n_c - 1;  // clamped rows are computed and discarded
         brow[q] = spec + (sd.c_off + fj) * (size_t)CBINS_PAD + 8 * g;
     }
-    // acc[q][r]: rows 4r + (lane / 16) of the 16-frame sub-tile q; twelve independent chains
-    double acc[4][3];
+    // two independent accumulator chains per sub-tile so consecutive MFMAs do not wait on each other
+    double4_t acc[4][2];
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int r = 0; r < 3; r++) acc[q][r] = 0.0;
-    // K loop in 32-bin blocks (two 16-bin steps of four k slots), software-pipelined by hand.
-    //  * The spectrogram (B) comes from HBM into a ring of three register blocks: two blocks (2 x 8 loads) are in flight
-    //    behind the one being multiplied -- a block is only 96 MFMAs = ~0.6 us of matrix pipe, far less than the loaded
-    //    HBM latency.
-    //  * The filter (A) comes from the L2-resident bank.  Vector-memory loads retire in order, so an A fetch issued after
-    //    a B prefetch could not be waited for without draining that prefetch; and a second register ring for A does not
-    //    fit.  A block's 3 KB of filter values therefore travel global -> LDS directly (no registers), two blocks ahead,
-    //    into a private three-slot ring per wavefront, and are read back (own counter) at the start of their block.
-    // No branch in the loop: the fetches past the end re-read the last block.
-    struct BBlock { float4_t b[2][4]; };
-    constexpr int KBLOCKS = CBINS_PAD / 32;
-    static_assert(CBINS_PAD % 32 == 0 && BANK_PITCH == CBINS_PAD && KBLOCKS % 3 == 0, "the loop below handles three blocks per trip");
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // lane L of a DMA instruction fetches 16 bytes = bins 8 gd + 4 ud + 2 hd (+0, +1) of filter row 4 r + id
-    const int id = lane & 3, gd = (lane >> 2) & 3, hd = (lane >> 4) & 1, ud = lane >> 5;
-    const double* __restrict__ a_src = bank + ((size_t)slot * BANK_ROWS + id) * BANK_PITCH + 8 * gd + 4 * ud + 2 * hd;
-    auto a_dma = [&](int blk, int ring) {
-        const int k0 = 32 * (blk < KBLOCKS ? blk : KBLOCKS - 1);
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-            __builtin_amdgcn_global_load_lds(a_src + (size_t)4 * r * BANK_PITCH + k0, &a_ring[wave_u][ring][r][0], 16, 0, 0);
+    for (int q = 0; q < 4; q++) { acc[q][0] = double4_t{0.0, 0.0, 0.0, 0.0}; acc[q][1] = double4_t{0.0, 0.0, 0.0, 0.0}; }
+    // K loop in 32-bin blocks (two 16-bin MFMA steps), software-pipelined over two register buffers: block j+1's ten
+    // loads are issued before block j's 32 MFMAs, so a wavefront always has a block in flight while it computes (with two
+    // wavefronts per SIMD, a load -> drain -> MFMA loop leaves the matrix pipe idle whenever the HBM latency exceeds one
+    // block's MFMA time).  Every load and every wait here is the compiler's.
+    //
+    // A faster variant of this loop (v_mfma_f64_4x4x4_4b_f64: three instructions cover the 12 chroma rows exactly and run
+    // at 77 instead of 61 TFLOP/s; spectrogram ring of three blocks and filter values staged through the LDS, all loads as
+    // asm statements with hand-counted s_waitcnt vmcnt) ran at 6.0 ms, passed every parity test -- and returned a wrong
+    // chroma row about once in 5 000 songs of a multi-chunk batch (tests/tools/determinism_check.py; the same MFMAs with
+    // compiler-managed loads are clean but take 9.1 ms, because the compiler then drains the whole queue per block).  The
+    // cause was not found; the variant is not shipped.
+    struct KBlock {
+        double4_t a[2];
+        float4 b[2][4];
     };
-    // lane (i, blk, g) reads rows 4 r + i at bins 8 g + 4 u + 2 h: DMA lane i + 4 g + 16 h + 32 u.  The read is an asm
-    // block: the compiler's dependence tracking for global->LDS transfers drains the WHOLE vector memory queue before a
-    // ds_read of such a buffer (it cannot tell the ring slots apart), which would also wait for the spectrogram
-    // prefetches.  wait_block() below has made sure the slot's DMA has landed.
-    const uint32_t a_rd = (uint32_t)(uintptr_t)&a_ring[wave_u][0][0][(lane & 3) + 4 * g];
-    struct AStep { double2_t a[3][2]; };  // [row group][k pair]
-    auto a_read = [&](int ring, int u, AStep& as) {
-        const uint32_t addr = a_rd + (uint32_t)ring * (uint32_t)sizeof(a_ring[0][0]) + 512u * (uint32_t)u;
-        asm volatile(
-            "ds_read_b128 %0, %6\n\t"
-            "ds_read_b128 %1, %6 offset:256\n\t"
-            "ds_read_b128 %2, %6 offset:1024\n\t"
-            "ds_read_b128 %3, %6 offset:1280\n\t"
-            "ds_read_b128 %4, %6 offset:2048\n\t"
-            "ds_read_b128 %5, %6 offset:2304\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(as.a[0][0]), "=&v"(as.a[0][1]), "=&v"(as.a[1][0]), "=&v"(as.a[1][1]), "=&v"(as.a[2][0]), "=&v"(as.a[2][1])
-            : "v"(addr)
-            : "memory");
-    };
-    // The spectrogram loads are asm statements too, so that NO wait in the loop is the compiler's: with global->LDS
-    // transfers in the queue its counter tracking falls back to vmcnt(0) for ordinary loads as well.  Every asm statement
-    // of the loop clobbers "memory": the hand-counted vmcnt values rely on the program order of these statements AND of
-    // the DMA intrinsics between them.
-    auto b_load = [&](int blk, BBlock& bb) {
-        const int k0 = 32 * (blk < KBLOCKS ? blk : KBLOCKS - 1);
+    auto k_load = [&](int k0, KBlock& kb) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float* p = brow[q] + k0;
-            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
-                         : "=&v"(bb.b[0][q]), "=&v"(bb.b[1][q])
-                         : "v"(p)
-                         : "memory");
-        }
-    };
-    // Everything issued before the spectrogram block B(j+1) has landed: in program order that is A(j) [3 transfers],
-    // B(j) [8 loads] and A(j+1) [3]; only B(j+1)'s 8 loads may still be in flight.  The block's registers pass through
-    // the statement so that none of their uses can be scheduled above it.
-    auto wait_block = [&](BBlock& bb) {
-        asm volatile("s_waitcnt vmcnt(8)"
-                     : "+v"(bb.b[0][0]), "+v"(bb.b[0][1]), "+v"(bb.b[0][2]), "+v"(bb.b[0][3]), "+v"(bb.b[1][0]),
-                       "+v"(bb.b[1][1]), "+v"(bb.b[1][2]), "+v"(bb.b[1][3])
-                     :
-                     : "memory");
-    };
-    auto step_mma = [&](const AStep& as, const BBlock& bb, int u) {
+        for (int u = 0; u < 2; u++) kb.a[u] = *reinterpret_cast<const double4_t*>(arow + k0 + 4 * u);
 #pragma unroll
-        for (int e = 0; e < 4; e++) {  // k slot of the lane's four consecutive bins: twelve independent MFMAs per slot
-            double sq[4];
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) kb.b[u][q] = *reinterpret_cast<const float4*>(brow[q] + k0 + 4 * u);
+    };
+    auto k_mma = [&](const KBlock& kb) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const double x = (double)bb.b[u][q][e];
-                sq[q] = x * x;
+                const float4 v = kb.b[u][q];
+                const double b0 = (double)v.x * (double)v.x, b1 = (double)v.y * (double)v.y;
+                const double b2 = (double)v.z * (double)v.z, b3 = (double)v.w * (double)v.w;
+                acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(kb.a[u].x, b0, acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(kb.a[u].y, b1, acc[q][1], 0, 0, 0);
+                acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(kb.a[u].z, b2, acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(kb.a[u].w, b3, acc[q][1], 0, 0, 0);
             }
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int r = 0; r < 3; r++)
-                    acc[q][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(as.a[r][e >> 1][e & 1], sq[q], acc[q][r], 0, 0, 0);
         }
     };
-    // one block: wait for its operands, read the filter values of its first step, THEN issue the transfers for the block
-    // two ahead (program order = retirement order: the next wait must not include them), then the 96 MFMAs
-    auto block = [&](int ring, BBlock& bcur, int blk_next, int ring_next, BBlock& bnext) {
-        AStep as;
-        wait_block(bcur);
-        a_read(ring, 0, as);
-        a_dma(blk_next, ring_next);
-        b_load(blk_next, bnext);
-        step_mma(as, bcur, 0);
-        a_read(ring, 1, as);
-        step_mma(as, bcur, 1);
-    };
-    BBlock b0, b1, b2;
-    a_dma(0, 0);
-    b_load(0, b0);
-    a_dma(1, 1);
-    b_load(1, b1);
+    constexpr int KBLOCKS = CBINS_PAD / 32;
+    static_assert(CBINS_PAD % 32 == 0 && BANK_PITCH == CBINS_PAD && KBLOCKS % 2 == 1, "pairs of blocks and one last block");
+    KBlock k0buf, k1buf;
+    k_load(0, k0buf);
 #pragma unroll 1
-    for (int blk = 0; blk < KBLOCKS; blk += 3) {
-        block(0, b0, blk + 2, 2, b2);
-        block(1, b1, blk + 3, 0, b0);
-        block(2, b2, blk + 4, 1, b1);
+    for (int kb = 0; kb + 2 < KBLOCKS; kb += 2) {
+        k_load(32 * (kb + 1), k1buf);
+        k_mma(k0buf);
+        k_load(32 * (kb + 2), k0buf);
+        k_mma(k1buf);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the (unused) fetches past the end
+    k_mma(k0buf);
     // Epilogue on all 64 lanes at once: the four C tiles go through LDS so that lane 16 q + i owns frame 16 q + i
     // (12 chroma values), instead of four passes of the f64 exp / template arithmetic on 16 active lanes each.
 #pragma unroll
     for (int q = 0; q < 4; q++) {
+        const double4_t cacc = acc[q][0] + acc[q][1];
         // C[row = g + 4r][col = i16]: rows are chroma classes, columns are frames
 #pragma unroll
-        for (int r = 0; r < 3; r++) tile_c[wave][q][i16][g + 4 * r] = acc[q][r];
+        for (int r = 0; r < 3; r++) tile_c[wave][q][i16][g + 4 * r] = cacc[r];
     }
     __builtin_amdgcn_wave_barrier();
     double feat[10];
