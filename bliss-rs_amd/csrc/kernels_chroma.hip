@@ -1006,6 +1006,7 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
         for (int q = 0; q < 4; q++)
 #pragma unroll
             for (int u = 0; u < 2; u++) kb.b[u][q] = *reinterpret_cast<const float4*>(brow[q] + k0 + 4 * u);
+        __builtin_amdgcn_sched_barrier(0);  // the block's loads stay where they are written: ahead of the previous block's MFMAs
     };
     auto k_mma = [&](const KBlock& kb) {
 #pragma unroll
