@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--ws-limit-gb", type=float, default=4.0)
+    ap.add_argument("--max-seconds", type=float, default=240.0, help="longest song")
     args = ap.parse_args()
     import torch
 
@@ -30,7 +31,7 @@ def main():
     ctx.set_workspace_limit(int(args.ws_limit_gb * (1 << 30)))
     rng = np.random.default_rng(args.seed)
     n = args.songs
-    lens = rng.integers(8192, 4 * 60 * 22050, n).astype(np.uint64)
+    lens = rng.integers(8192, int(args.max_seconds * 22050), n).astype(np.uint64)
     padded = (lens + np.uint64(63)) // np.uint64(64) * np.uint64(64)
     offs = np.zeros(n, np.uint64)
     offs[1:] = np.cumsum(padded)[:-1]
