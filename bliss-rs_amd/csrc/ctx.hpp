@@ -168,6 +168,7 @@ struct Prof {  // HIP events around one launch, on the stream the kernel is laun
     }
 };
 
+constexpr uint32_t MAX_SONGS_PER_CHUNK = 65535;  // grid.y of the (run, song) launches
 constexpr size_t PIPELINE_MIN_CHUNK_BYTES = 512u << 20;  // a pipeline chunk below ~16 three-minute songs no longer fills the GPU
 
 int default_ctx(blissgpu_ctx** out);  // process-wide context on device 0 (created on first use)

@@ -668,7 +668,8 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
     const uint32_t b_lo = ts->b_lo, b_hi = ts->b_hi;
     if (ts->n_peaks == 0) return;
     const uint32_t cand_off = ts->cand_off;
-    const bool pooled = ts->cand_cap != 0;  // false: the pool was exhausted, tune_final re-scans the records instead
+    const uint32_t cand_cap = ts->cand_cap;
+    const bool pooled = cand_cap != 0;  // false: the pool was exhausted, tune_final re-scans the records instead
     if (tid < N_TUNING) hist[tid] = 0;
     __syncthreads();
     uint32_t n_slow = 0;  // wave-uniform
@@ -686,8 +687,10 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
                 if (b > b_hi) {
                     atomicAdd(&hist[pitch_bin(pitch)], 1u);
                 } else if (b >= b_lo) {
+                    // The pool slice was sized from the STFT-time histogram of these very bins; should the count ever
+                    // disagree, the surplus stays out of the neighbour's slice and tune_final_kernel sees n_cand != cand_cap.
                     const uint32_t slot = atomicAdd(&ts->n_cand, 1u);
-                    if (pooled) {
+                    if (pooled && slot < cand_cap) {
                         cand_mag[cand_off + slot] = mag;
                         cand_pb[cand_off + slot] = (uint8_t)pitch_bin(pitch);
                     }
@@ -830,7 +833,9 @@ __global__ __launch_bounds__(256) void tune_final_kernel(const SongDesc* __restr
     const uint32_t r_lo = (total - 1) / 2, r_hi = total - 1 - r_lo;
     const uint32_t k_lo = r_lo - ts->below, k_hi = r_hi - ts->below;
     const uint32_t b_lo = ts->b_lo, b_hi = ts->b_hi;
-    const bool pooled = ts->cand_cap != 0;
+    // pooled candidates are trusted only when pass 2 filed exactly as many as the histogram promised; anything else
+    // (never observed) takes the exact re-scan of the records
+    const bool pooled = ts->cand_cap != 0 && nc == ts->cand_cap;
     const double* v = cand_mag + ts->cand_off;
     const uint8_t* pb = cand_pb + ts->cand_off;
 

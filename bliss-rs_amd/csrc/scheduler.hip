@@ -3,7 +3,7 @@
 // analysis (src/song/mod.rs:432-491).
 //
 //   plan      songs are ordered by length (longest first: "length bucketing") and cut into chunks whose scratch
-//             workspace fits one of the context's TWO chunk slots (big batches into at least four chunks);
+//             workspace fits one of the context's TWO chunk slots;
 //   schedule  a chunk is enqueued in two halves -- front: the FFT kernels on the main stream, its per-song tails and its
 //             tuning estimate on two high-priority side streams; back: the chroma contraction and the row assembly -- and
 //             the back half of chunk k follows the front half of chunk k + 1, so the latency-bound kernels of one chunk
@@ -527,7 +527,8 @@ int blissgpu_analyze_batch_device(blissgpu_ctx* c, const float* d_pcm, const uin
         uint32_t b0 = 0;
         for (uint32_t i = 0; i < n_songs; i++) {
             const size_t sb = song_ws_bytes(songs[i]);
-            if (i > b0 && bytes + sb > limit) { todo.push_back({b0, i}); b0 = i; bytes = 0; }
+            // a chunk also never holds more songs than one grid dimension addresses (the beat tracker's (run, song) grid)
+            if (i > b0 && (bytes + sb > limit || i - b0 >= MAX_SONGS_PER_CHUNK)) { todo.push_back({b0, i}); b0 = i; bytes = 0; }
             bytes += sb;
         }
         todo.push_back({b0, n_songs});

@@ -1,0 +1,73 @@
+// kbench.cpp -- per-kernel timing of one analysis batch through the C ABI, without Python: the quick A/B loop for kernel
+// work on the GPU box (a fresh box pays 1-2 minutes for its first `import torch`; this pays nothing).
+//   build: g++ -std=c++17 -O1 -o tests/tools/kbench tests/tools/kbench.cpp -ldl
+//   usage: kbench <libblissgpu.so> [songs=256] [seconds=180] [steps=3] [ragged=0]
+// Prints ms per kernel per step (HIP events on the stream each kernel runs on; set BLISSGPU_SERIAL=1 for every kernel
+// alone), the step's wall time, and an FNV-1a hash of the feature rows (two builds that agree bit for bit print the same hash).
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/blissgpu.h"
+
+#define SYM(name) auto p_##name = (decltype(&name))dlsym(h, #name); if (!p_##name) { std::fprintf(stderr, "missing %s\n", #name); return 2; }
+#define OK(expr) do { int rc_ = (expr); if (rc_) { std::fprintf(stderr, "FAILED %s -> %d (%s)\n", #expr, rc_, p_blissgpu_last_error()); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: kbench <lib> [songs] [seconds] [steps] [ragged]\n"); return 2; }
+    void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+    if (!h) { std::fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+    const uint32_t n = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 256;
+    const double seconds = argc > 3 ? std::atof(argv[3]) : 180.0;
+    const int steps = argc > 4 ? std::atoi(argv[4]) : 3;
+    const int ragged = argc > 5 ? std::atoi(argv[5]) : 0;
+    SYM(blissgpu_last_error) SYM(blissgpu_ctx_create) SYM(blissgpu_ctx_destroy) SYM(blissgpu_malloc) SYM(blissgpu_free)
+    SYM(blissgpu_synth_white_noise_device) SYM(blissgpu_analyze_batch_device) SYM(blissgpu_ctx_synchronize)
+    SYM(blissgpu_profile_enable) SYM(blissgpu_profile_reset) SYM(blissgpu_profile_kernel_count) SYM(blissgpu_profile_kernel_name)
+    SYM(blissgpu_profile_get) SYM(blissgpu_memcpy_d2h)
+    blissgpu_ctx* c = nullptr;
+    OK(p_blissgpu_ctx_create(0, &c));
+    std::vector<uint64_t> offs(n), lens(n);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t len = (uint64_t)(seconds * 22050.0);
+        if (ragged) len = 8192 + (uint64_t)((i * 2654435761u) % (uint32_t)(len - 8192 + 1));
+        offs[i] = total; lens[i] = len; total += (len + 63) / 64 * 64;
+    }
+    float *d_pcm = nullptr, *d_out = nullptr;
+    OK(p_blissgpu_malloc((void**)&d_pcm, total * 4));
+    OK(p_blissgpu_malloc((void**)&d_out, (uint64_t)n * 23 * 4));
+    OK(p_blissgpu_synth_white_noise_device(c, d_pcm, offs.data(), lens.data(), n, 0));
+    OK(p_blissgpu_analyze_batch_device(c, d_pcm, offs.data(), lens.data(), n, 2, d_out, nullptr));  // warm-up (allocations)
+    OK(p_blissgpu_ctx_synchronize(c));
+    // plain steps: the wall time of a step as a caller sees it
+    auto t0 = std::chrono::steady_clock::now();
+    for (int s = 0; s < steps; s++) OK(p_blissgpu_analyze_batch_device(c, d_pcm, offs.data(), lens.data(), n, 2, d_out, nullptr));
+    OK(p_blissgpu_ctx_synchronize(c));
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / steps;
+    // profiled steps: HIP events around every launch
+    OK(p_blissgpu_profile_enable(c, 1));
+    OK(p_blissgpu_profile_reset(c));
+    for (int s = 0; s < steps; s++) OK(p_blissgpu_analyze_batch_device(c, d_pcm, offs.data(), lens.data(), n, 2, d_out, nullptr));
+    OK(p_blissgpu_ctx_synchronize(c));
+    std::printf("%s songs=%u seconds=%g ragged=%d step_ms=%.3f", argv[1], n, seconds, ragged, wall_ms);
+    for (int k = 0; k < p_blissgpu_profile_kernel_count(); k++) {
+        double ms = 0; uint64_t launches = 0;
+        OK(p_blissgpu_profile_get(c, k, &ms, &launches));
+        if (launches) std::printf(" %s=%.3f", p_blissgpu_profile_kernel_name(k), ms / steps);
+    }
+    std::vector<float> rows((size_t)n * 23);
+    OK(p_blissgpu_memcpy_d2h(c, rows.data(), d_out, rows.size() * 4));
+    uint64_t hash = 1469598103934665603ull;
+    const unsigned char* b = (const unsigned char*)rows.data();
+    for (size_t i = 0; i < rows.size() * 4; i++) { hash ^= b[i]; hash *= 1099511628211ull; }
+    std::printf(" hash=%016llx row0=[%.6f %.6f %.6f ... %.6f]\n", (unsigned long long)hash, rows[0], rows[1], rows[2], rows[22]);
+    p_blissgpu_free(d_pcm); p_blissgpu_free(d_out);
+    p_blissgpu_ctx_destroy(c);
+    return 0;
+}
