@@ -61,6 +61,16 @@ int main(int argc, char** argv) {
         OK(p_blissgpu_profile_get(c, k, &ms, &launches));
         if (launches) std::printf(" %s=%.3f", p_blissgpu_profile_kernel_name(k), ms / steps);
     }
+    if (auto p_trace = (int (*)(unsigned long long*, int))dlsym(h, "blissgpu_debug_stft_trace")) {  // -DSTFT_TRACE builds only
+        unsigned long long tr[32];
+        if (p_trace(tr, 1) == 0) {
+            unsigned long long tot = 0;
+            for (int k = 0; k < 32; k++) tot += tr[k];
+            std::printf("\n  stft trace (%% of wave 0's cycles per mark):");
+            for (int k = 0; k < 32; k++) if (tr[k]) std::printf(" [%d]=%.1f", k, 100.0 * (double)tr[k] / (double)tot);
+            std::printf("  total cycles/frame-ish=%.0f", (double)tot);
+        }
+    }
     std::vector<float> rows((size_t)n * 23);
     OK(p_blissgpu_memcpy_d2h(c, rows.data(), d_out, rows.size() * 4));
     uint64_t hash = 1469598103934665603ull;
