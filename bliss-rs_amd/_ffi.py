@@ -57,6 +57,8 @@ SIGNATURES = {
     "blissgpu_closest_to_songs_device": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp,
                                                    _vp]),
     "blissgpu_song_to_song_device": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp]),
+    "blissgpu_shard_plan": (C.c_int, [_u64p, C.c_uint32, C.c_uint32, _u32p]),
+    "blissgpu_row_block": (None, [C.c_uint64, C.c_uint32, C.c_uint32, _u64p, _u64p]),
     "blissgpu_node_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),
     "blissgpu_node_destroy": (C.c_int, [_vp]),
     "blissgpu_node_device_count": (C.c_int, [_vp]),

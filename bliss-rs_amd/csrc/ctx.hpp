@@ -177,8 +177,9 @@ int default_ctx(blissgpu_ctx** out);  // process-wide context on device 0 (creat
 void scheduler_release(blissgpu_ctx* c);
 // Host PCM feed: song i = ptrs[i] (host memory), lengths[i] FRAMES of `channels` interleaved samples of
 // `bytes_per_sample` (4: f32, 2: s16); channels > 1 are downmixed on the device.
+// d_rows (device, n_songs x feature_count, may be NULL) receives a copy of the rows that stays on the device.
 int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t* lengths, uint32_t n_songs,
                        int bytes_per_sample, uint32_t channels, uint32_t features_version, float* out, int32_t* status,
-                       const char* who);
+                       const char* who, float* d_rows = nullptr);
 
 }  // namespace bg

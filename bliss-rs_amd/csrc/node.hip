@@ -6,6 +6,12 @@
 // RCCL is loaded at run time (dlopen) the first time a node is created: libblissgpu.so keeps loading on machines without
 // it, and inside a torch process the copy torch already mapped is reused.  Without RCCL blissgpu_node_create fails with
 // BLISSGPU_ERR_RCCL -- there is no fallback path.
+//
+// Loopback ranks: a device list that names one ordinal more than once (several contexts sharing a GPU) cannot have an
+// RCCL communicator (ncclCommInitAll rejects duplicate devices), and needs none: every rank's buffers are reachable
+// from every other rank's stream, so the gather is R x R device-to-device copies ordered by events.  Everything else --
+// the plan, the padded rank-major layout with perm = -1 slots, the scatter kernel, the row-block pairwise -- is the code
+// the RCCL form runs, which makes the N > 1 paths testable on a one-GPU box.
 #include <dlfcn.h>
 #include <string.h>
 #include <rccl/rccl.h>  // types and prototypes only: every call goes through the pointers resolved below
@@ -77,6 +83,8 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
 struct blissgpu_node {
     std::mutex mu;
     int n = 0;
+    bool loopback = false;              // some device ordinal appears twice: gather by device-to-device copies, no RCCL
+    std::vector<hipEvent_t> ev_rows;    // per rank: its local rows are in send[r] (loopback gather)
     std::vector<int> devices;
     std::vector<blissgpu_ctx*> ctx;
     std::vector<ncclComm_t> comm;
@@ -94,6 +102,7 @@ namespace {
 // bliss_rs_amd.shard.shard_songs: greedy longest-first assignment balancing the samples per rank; ties -> fewest songs ->
 // lowest rank.  Deterministic, so every host computes the same plan.
 void shard_plan(const uint64_t* lengths, uint32_t n_songs, int world, std::vector<std::vector<uint32_t>>& shards) {
+    // (exported device-free as blissgpu_shard_plan)
     std::vector<uint32_t> order(n_songs);
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lengths[a] > lengths[b]; });
@@ -119,9 +128,12 @@ int gather_rows(blissgpu_node* nd) {
     std::vector<int32_t> perm((size_t)R * n_max, -1);
     for (int r = 0; r < R; r++)
         for (size_t j = 0; j < nd->shard[r].size(); j++) perm[(size_t)r * n_max + j] = (int32_t)nd->shard[r][j];
+    // every rank's context is held while its stream is being fed (the header promises per-context serialisation);
+    // always in rank order, so two nodes sharing contexts could not deadlock either
+    std::vector<std::unique_lock<std::recursive_mutex>> held;
+    for (int r = 0; r < R; r++) held.emplace_back(nd->ctx[r]->mu);
     for (int r = 0; r < R; r++) {
         blissgpu_ctx* c = nd->ctx[r];
-        std::lock_guard<std::recursive_mutex> lk(c->mu);
         HIP_TRY(hipSetDevice(c->device));
         int rc = nd->recv[r].ensure((size_t)R * n_max * d);
         if (!rc) rc = nd->full[r].ensure(std::max<size_t>(1, (size_t)nd->n_songs * d));
@@ -130,12 +142,30 @@ int gather_rows(blissgpu_node* nd) {
         HIP_TRY(hipMemcpyAsync(nd->perm[r].p, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));  // `perm` is a local: the copy must have left it
     }
-    // padded fixed-size all-gather (<= ~1 MB per rank at library sizes: latency-bound on xGMI); single-process
-    // multi-device collectives must be issued inside one group
-    RCCL_TRY(g_rccl.GroupStart());
-    for (int r = 0; r < R; r++)
-        RCCL_TRY(g_rccl.AllGather(nd->send[r].p, nd->recv[r].p, (size_t)n_max * d, ncclFloat, nd->comm[r], nd->ctx[r]->stream));
-    RCCL_TRY(g_rccl.GroupEnd());
+    const size_t block = (size_t)n_max * d;  // padded fixed-size blocks (<= ~1 MB per rank at library sizes: latency-bound on xGMI)
+    if (nd->loopback) {
+        for (int q = 0; q < R; q++) {
+            HIP_TRY(hipSetDevice(nd->ctx[q]->device));
+            HIP_TRY(hipEventRecord(nd->ev_rows[q], nd->ctx[q]->stream));
+        }
+        for (int r = 0; r < R; r++) {
+            blissgpu_ctx* c = nd->ctx[r];
+            HIP_TRY(hipSetDevice(c->device));
+            for (int q = 0; q < R; q++) {
+                if (q != r) HIP_TRY(hipStreamWaitEvent(c->stream, nd->ev_rows[q], 0));
+                HIP_TRY(hipMemcpyAsync(nd->recv[r].p + (size_t)q * block, nd->send[q].p, block * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
+    } else {
+        // single-process multi-device collectives must be issued inside one group; the group is closed on every path
+        ncclResult_t nr = g_rccl.GroupStart();
+        if (nr != ncclSuccess) return fail(BLISSGPU_ERR_RCCL, "ncclGroupStart", g_rccl.GetErrorString(nr));
+        for (int r = 0; r < R && nr == ncclSuccess; r++)
+            nr = g_rccl.AllGather(nd->send[r].p, nd->recv[r].p, block, ncclFloat, nd->comm[r], nd->ctx[r]->stream);
+        const ncclResult_t ne = g_rccl.GroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) return fail(BLISSGPU_ERR_RCCL, "ncclAllGather", g_rccl.GetErrorString(nr));
+    }
     for (int r = 0; r < R; r++) {
         blissgpu_ctx* c = nd->ctx[r];
         HIP_TRY(hipSetDevice(c->device));
@@ -153,7 +183,7 @@ int prepare(blissgpu_node* nd, const uint64_t* lengths, const uint32_t* rank_of_
     if (rank_of_song) {
         nd->shard.assign(nd->n, {});
         for (uint32_t i = 0; i < n_songs; i++) {
-            if ((int)rank_of_song[i] >= nd->n) return fail(BLISSGPU_ERR_INVALID, "blissgpu_node", "rank_of_song out of range");
+            if (rank_of_song[i] >= (uint32_t)nd->n) return fail(BLISSGPU_ERR_INVALID, "blissgpu_node", "rank_of_song out of range");
             nd->shard[rank_of_song[i]].push_back(i);
         }
     } else {
@@ -176,22 +206,47 @@ int prepare(blissgpu_node* nd, const uint64_t* lengths, const uint32_t* rank_of_
 
 extern "C" {
 
+int blissgpu_shard_plan(const uint64_t* lengths, uint32_t n_songs, uint32_t world, uint32_t* rank_of_song) {
+    if (world < 1 || world > 4096 || (n_songs && (!lengths || !rank_of_song)))
+        return fail(BLISSGPU_ERR_INVALID, "blissgpu_shard_plan", "bad arguments");
+    std::vector<std::vector<uint32_t>> shards;
+    shard_plan(lengths, n_songs, (int)world, shards);
+    for (uint32_t r = 0; r < world; r++)
+        for (uint32_t i : shards[r]) rank_of_song[i] = r;
+    return BLISSGPU_OK;
+}
+
 int blissgpu_node_create(int n_devices, const int* devices, blissgpu_node** out) {
     if (!out || n_devices < 1 || n_devices > 64) return fail(BLISSGPU_ERR_INVALID, "blissgpu_node_create", "bad arguments");
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count < n_devices)
-        return fail(BLISSGPU_ERR_NO_DEVICE, "blissgpu_node_create", "fewer HIP devices than requested");
-    int rc = load_rccl();
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
+        return fail(BLISSGPU_ERR_NO_DEVICE, "blissgpu_node_create", "no HIP device");
+    std::vector<int> devs;
+    bool loopback = false;
+    for (int r = 0; r < n_devices; r++) {
+        const int dv = devices ? devices[r] : r;
+        if (dv < 0 || dv >= count) return fail(BLISSGPU_ERR_NO_DEVICE, "blissgpu_node_create", "fewer HIP devices than requested");
+        loopback = loopback || std::find(devs.begin(), devs.end(), dv) != devs.end();
+        devs.push_back(dv);
+    }
+    int rc = loopback ? BLISSGPU_OK : load_rccl();
     if (rc) return rc;
     blissgpu_node* nd = new blissgpu_node();
     nd->n = n_devices;
-    for (int r = 0; r < n_devices; r++) nd->devices.push_back(devices ? devices[r] : r);
+    nd->loopback = loopback;
+    nd->devices = devs;
+    nd->ev_rows.assign(n_devices, nullptr);
     nd->ctx.assign(n_devices, nullptr);
     nd->comm.assign(n_devices, nullptr);
     nd->send.resize(n_devices); nd->recv.resize(n_devices); nd->full.resize(n_devices); nd->block.resize(n_devices);
     nd->perm.resize(n_devices); nd->dm.resize(n_devices);
     for (int r = 0; r < n_devices && !rc; r++) rc = blissgpu_ctx_create(nd->devices[r], &nd->ctx[r]);
-    if (!rc) {
+    for (int r = 0; r < n_devices && !rc; r++) {
+        hipError_t e = hipSetDevice(nd->devices[r]);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&nd->ev_rows[r], hipEventDisableTiming);
+        if (e != hipSuccess) rc = fail(BLISSGPU_ERR_HIP, "hipEventCreate", hipGetErrorString(e));
+    }
+    if (!rc && !loopback) {
         ncclResult_t nr = g_rccl.CommInitAll(nd->comm.data(), n_devices, nd->devices.data());
         if (nr != ncclSuccess) rc = fail(BLISSGPU_ERR_RCCL, "ncclCommInitAll", g_rccl.GetErrorString(nr));
     }
@@ -205,6 +260,7 @@ int blissgpu_node_destroy(blissgpu_node* nd) {
     for (int r = 0; r < nd->n; r++) {
         if (nd->ctx[r]) { (void)hipSetDevice(nd->ctx[r]->device); (void)hipStreamSynchronize(nd->ctx[r]->stream); }
         if (nd->comm[r]) (void)g_rccl.CommDestroy(nd->comm[r]);
+        if (nd->ev_rows[r]) (void)hipEventDestroy(nd->ev_rows[r]);
         nd->send[r].release(); nd->recv[r].release(); nd->full[r].release(); nd->block[r].release();
         nd->perm[r].release(); nd->dm[r].release();
         if (nd->ctx[r]) blissgpu_ctx_destroy(nd->ctx[r]);
@@ -217,19 +273,25 @@ int blissgpu_node_device_count(blissgpu_node* nd) { return nd ? nd->n : 0; }
 blissgpu_ctx* blissgpu_node_ctx(blissgpu_node* nd, int rank) { return (nd && rank >= 0 && rank < nd->n) ? nd->ctx[rank] : nullptr; }
 
 int blissgpu_node_shard(blissgpu_node* nd, const uint64_t* lengths, uint32_t n_songs, uint32_t* rank_of_song) {
-    if (!nd || (n_songs && (!lengths || !rank_of_song))) return fail(BLISSGPU_ERR_INVALID, "blissgpu_node_shard", "NULL argument");
-    std::vector<std::vector<uint32_t>> shards;
-    shard_plan(lengths, n_songs, nd->n, shards);
-    for (int r = 0; r < nd->n; r++)
-        for (uint32_t i : shards[r]) rank_of_song[i] = (uint32_t)r;
-    return BLISSGPU_OK;
+    if (!nd) return fail(BLISSGPU_ERR_INVALID, "blissgpu_node_shard", "NULL argument");
+    return blissgpu_shard_plan(lengths, n_songs, (uint32_t)nd->n, rank_of_song);
 }
 
-void blissgpu_node_row_block(blissgpu_node* nd, uint64_t n_rows, int rank, uint64_t* lo, uint64_t* hi) {
-    const uint64_t world = nd ? (uint64_t)nd->n : 1, base = n_rows / world, rem = n_rows % world, r = (uint64_t)rank;
+void blissgpu_row_block(uint64_t n_rows, uint32_t world, uint32_t rank, uint64_t* lo, uint64_t* hi) {
+    if (world == 0) world = 1;
+    if (rank >= world) {  // no such rank: an empty block behind the matrix
+        if (lo) *lo = n_rows;
+        if (hi) *hi = n_rows;
+        return;
+    }
+    const uint64_t base = n_rows / world, rem = n_rows % world, r = rank;
     const uint64_t l = r * base + std::min(r, rem);
     if (lo) *lo = l;
     if (hi) *hi = l + base + (r < rem ? 1 : 0);
+}
+
+void blissgpu_node_row_block(blissgpu_node* nd, uint64_t n_rows, int rank, uint64_t* lo, uint64_t* hi) {
+    blissgpu_row_block(n_rows, nd ? (uint32_t)nd->n : 1u, rank < 0 ? 0xFFFFFFFFu : (uint32_t)rank, lo, hi);
 }
 
 int blissgpu_node_analyze_device(blissgpu_node* nd, const float* const* d_pcm, const uint64_t* offsets, const uint64_t* lengths,
@@ -274,8 +336,9 @@ int blissgpu_node_analyze(blissgpu_node* nd, const float* pcm, const uint64_t* o
             std::vector<uint64_t> lens(mine.size());
             for (size_t j = 0; j < mine.size(); j++) { ptrs[j] = pcm + offsets[mine[j]]; lens[j] = lengths[mine[j]]; }
             rows[r].resize(mine.size() * (size_t)d);
+            // the rows go to the host (the caller's `out`) AND stay on the device in send[r] for the gather
             rcs[r] = analyze_host_songs(nd->ctx[r], ptrs.data(), lens.data(), (uint32_t)mine.size(), 4, 1, features_version,
-                                        rows[r].data(), nullptr, "blissgpu_node_analyze");
+                                        rows[r].data(), nullptr, "blissgpu_node_analyze", nd->send[r].p);
             if (rcs[r]) errs[r] = blissgpu_last_error();
         });
     for (auto& t : th) t.join();
@@ -284,11 +347,6 @@ int blissgpu_node_analyze(blissgpu_node* nd, const float* pcm, const uint64_t* o
     for (int r = 0; r < nd->n; r++) {
         const auto& mine = nd->shard[r];
         for (size_t j = 0; j < mine.size(); j++) memcpy(out + (size_t)mine[j] * d, rows[r].data() + j * d, d * sizeof(float));
-        if (mine.empty()) continue;
-        blissgpu_ctx* c = nd->ctx[r];
-        HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipMemcpyAsync(nd->send[r].p, rows[r].data(), rows[r].size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
     }
     if (status)
         for (uint32_t i = 0; i < n_songs; i++) status[i] = lengths[i] >= (uint64_t)MIN_SAMPLES ? BLISSGPU_SONG_OK : BLISSGPU_SONG_TOO_SHORT;

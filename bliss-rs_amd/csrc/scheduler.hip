@@ -273,7 +273,7 @@ void scheduler_release(blissgpu_ctx* c) {
 // ------------------------------------------------------------------------------------------------------------------
 int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t* lengths, uint32_t n_songs,
                        int bytes_per_sample, uint32_t channels, uint32_t features_version, float* out, int32_t* status,
-                       const char* who) {
+                       const char* who, float* d_rows) {
     const uint32_t d = blissgpu_feature_count(features_version);
     if (!d) return fail(BLISSGPU_ERR_INVALID, who, "features_version must be 1 or 2");
     if (channels == 0 || channels > 8) return fail(BLISSGPU_ERR_INVALID, who, "channels must be 1..8");
@@ -347,6 +347,8 @@ int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t*
         rc = blissgpu_analyze_batch_device(c, f.pcm[b].p, g.doff.data(), g.dlen.data(), g.n, features_version, f.out[b].p, nullptr);
         if (rc) break;
         e = hipMemcpyAsync(out + (size_t)g.i0 * d, f.out[b].p, (size_t)g.n * d * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && d_rows)
+            e = hipMemcpyAsync(d_rows + (size_t)g.i0 * d, f.out[b].p, (size_t)g.n * d * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
         if (e == hipSuccess) e = hipEventRecord(f.ev_done[b], c->stream);
         // the next group's transfer overlaps this group's kernels (pageable sources block the host here, not the GPU)
         if (e == hipSuccess && gi + 1 < groups.size()) e = upload(gi + 1);

@@ -28,6 +28,20 @@ def shard_songs(lengths: Sequence[int], world_size: int) -> List[np.ndarray]:
     return [np.array(sorted(s), dtype=np.int64) for s in shards]
 
 
+def shard_plan(lengths: Sequence[int], world_size: int) -> np.ndarray:
+    """rank_of_song as computed by the C ABI (blissgpu_shard_plan: device-free, the plan blissgpu_node_* uses); the
+    same assignment as shard_songs, which is the readable statement of the rule."""
+    import ctypes as C
+
+    from . import _ffi
+
+    lengths = np.ascontiguousarray(lengths, dtype=np.uint64)
+    ranks = np.empty(len(lengths), np.uint32)
+    _ffi.check(_ffi.lib().blissgpu_shard_plan(lengths.ctypes.data_as(C.POINTER(C.c_uint64)), len(lengths), world_size,
+                                              ranks.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return ranks
+
+
 def all_gather_features(local_rows, local_indices, n_total: int, group=None, n_local_max=None):
     """All-gather ragged [n_local, d] feature blocks and scatter them to their global rows.
 
@@ -69,7 +83,7 @@ def all_gather_features(local_rows, local_indices, n_total: int, group=None, n_l
 
 
 def row_block(n_rows: int, rank: int, world_size: int):
-    """Row range [lo, hi) of the pairwise-distance matrix computed by `rank`."""
+    """Row range [lo, hi) of the pairwise-distance matrix computed by `rank` (blissgpu_row_block is the C form)."""
     base, rem = divmod(n_rows, world_size)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)

@@ -184,8 +184,16 @@ int blissgpu_feature_weights(uint32_t features_version, float *M);
  * fails with BLISSGPU_ERR_RCCL.  (bliss_rs_amd/shard.py is the one-process-per-GPU form of the same plan on
  * torch.distributed.) */
 typedef struct blissgpu_node blissgpu_node;
-/* devices: HIP ordinals (NULL = 0 .. n_devices-1).  Creates one context per device and the RCCL communicators
- * (ncclCommInitAll). */
+/* The plan, device-free (no HIP call, no context): rank_of_song[i] = rank in [0, world) that analyses song i.  Greedy
+ * longest-first assignment balancing the samples per rank, ties -> fewest songs -> lowest rank; deterministic, so every
+ * host and every process computes the same plan (bliss_rs_amd.shard.shard_songs is the same function). */
+int blissgpu_shard_plan(const uint64_t *lengths, uint32_t n_songs, uint32_t world, uint32_t *rank_of_song);
+/* Rows [lo, hi) of an n_rows-row distance matrix computed by `rank` of `world` (device-free; rank >= world: empty). */
+void blissgpu_row_block(uint64_t n_rows, uint32_t world, uint32_t rank, uint64_t *lo, uint64_t *hi);
+/* devices: HIP ordinals (NULL = 0 .. n_devices-1).  Creates one context per rank and the RCCL communicators
+ * (ncclCommInitAll).  A list that names an ordinal more than once creates LOOPBACK ranks -- several contexts sharing a
+ * GPU: RCCL cannot (and need not) connect them, the gather is done with device-to-device copies; everything else is
+ * the same code.  That is how the N > 1 plan / padding / scatter / row-block paths are tested on a one-GPU box. */
 int blissgpu_node_create(int n_devices, const int *devices, blissgpu_node **node);
 int blissgpu_node_destroy(blissgpu_node *node);
 int blissgpu_node_device_count(blissgpu_node *node);

@@ -204,3 +204,63 @@ def test_cpp_host_mirror_compiles(tmp_path, bliss):
     if not torch.cuda.is_available():
         out = subprocess.run([str(exe), "a", "b"], capture_output=True, text=True)
         assert out.returncode != 0 and "no usable HIP device" in out.stderr
+
+
+# ---------------------------------------------------------------------------------------------
+# the sharding plan of the C ABI (device-free) against the torch.distributed form, at the sizes
+# configs[2] / configs[4] shard at
+# ---------------------------------------------------------------------------------------------
+def _config4_lengths(n_total=50000, seed=20260927):
+    """bench.py's mixed_lengths: configs[4], durations uniform 30 s - 10 min at 22 050 Hz, one seeded draw"""
+    rng = np.random.default_rng(seed)
+    return rng.integers(30 * 22050, 600 * 22050 + 1, n_total).astype(np.uint64)
+
+
+def test_c_shard_plan_equals_shard_songs_on_the_config4_draw(bliss):
+    from bliss_rs_amd.shard import shard_plan, shard_songs
+
+    lengths = _config4_lengths()
+    for world in (1, 2, 4, 8):
+        ranks = shard_plan(lengths, world)
+        shards = shard_songs(lengths, world)
+        assert sum(len(s) for s in shards) == len(lengths)
+        for r, s in enumerate(shards):
+            assert np.array_equal(np.flatnonzero(ranks == r), s), (world, r)
+        load = np.array([lengths[ranks == r].sum() for r in range(world)], dtype=np.float64)
+        assert load.max() - load.min() <= lengths.max()  # greedy longest-first: within one song of each other
+
+
+def test_c_shard_plan_edge_cases(bliss):
+    from bliss_rs_amd.shard import shard_plan, shard_songs
+    import ctypes as C
+    from bliss_rs_amd import _ffi
+
+    cases = [
+        [],                                   # nothing to shard
+        [5000],                               # fewer songs than ranks
+        [7, 7, 7, 7, 7, 7, 7, 7, 7],          # all ties: fewest songs, then lowest rank
+        [0, 0, 10, 0, 3, 3, 3],               # zero-length entries still get a rank
+        list(range(1, 40)),                   # ascending
+        [3969000] * 1250,                     # configs[2]: one GPU's share of equal songs
+    ]
+    for lengths in cases:
+        for world in (1, 2, 3, 8):
+            ranks = shard_plan(lengths, world)
+            assert len(ranks) == len(lengths) and (len(lengths) == 0 or ranks.max() < world)
+            for r, s in enumerate(shard_songs(lengths, world)):
+                assert np.array_equal(np.flatnonzero(ranks == r), s), (lengths[:5], world, r)
+    L = _ffi.lib()
+    assert L.blissgpu_shard_plan(None, 0, 0, None) == _ffi.ERR_INVALID  # world = 0
+    # row blocks tile the matrix for every world size, ragged remainders included
+    from bliss_rs_amd.shard import row_block
+    for n in (0, 1, 7, 100003):
+        for world in (1, 2, 8):
+            lo, hi = C.c_uint64(), C.c_uint64()
+            prev = 0
+            for r in range(world):
+                L.blissgpu_row_block(n, world, r, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == row_block(n, r, world) and lo.value == prev
+                prev = hi.value
+            assert prev == n
+            L.blissgpu_row_block(n, world, world, C.byref(lo), C.byref(hi))  # no such rank: empty
+            assert lo.value == hi.value == n
