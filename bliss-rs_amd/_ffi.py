@@ -34,6 +34,9 @@ SIGNATURES = {
     "blissgpu_ctx_set_workspace_limit": (C.c_int, [_vp, C.c_uint64]),
     "blissgpu_ctx_get_workspace_limit": (C.c_uint64, [_vp]),
     "blissgpu_ctx_synchronize": (C.c_int, [_vp]),
+    "blissgpu_default_device_count": (C.c_int, []),
+    "blissgpu_default_device": (C.c_int, [C.c_int]),
+    "blissgpu_default_device_batches": (C.c_uint64, [C.c_int]),
     "blissgpu_feature_count": (C.c_uint32, [C.c_uint32]),
     "blissgpu_analyze": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _i32p]),
     "blissgpu_analyze_interleaved": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, _vp, _i32p]),

@@ -82,22 +82,76 @@ int build_tables(blissgpu_ctx* c) {
     return BLISSGPU_OK;
 }
 
+// Process-wide default contexts of the entry points that take no context: one per visible HIP device, created on first
+// use.  BLISSGPU_DEFAULT_DEVICES="0,2,3" restricts / orders them (like HIP_VISIBLE_DEVICES, but for this library only);
+// an ordinal may be named more than once (several contexts sharing a GPU -- how the multi-context front is tested on a
+// one-GPU box).
 std::mutex g_default_mu;
-blissgpu_ctx* g_default_ctx = nullptr;
+std::vector<int> g_default_devices;
+std::vector<blissgpu_ctx*> g_default_ctxs;
+std::vector<uint64_t> g_default_batches;
+bool g_default_init = false;
+
+void default_init_locked() {
+    if (g_default_init) return;
+    g_default_init = true;
+    if (const char* e = getenv("BLISSGPU_DEFAULT_DEVICES")) {
+        for (const char* p = e; *p;) {
+            char* end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            if (v >= 0 && v < 4096 && g_default_devices.size() < 64) g_default_devices.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') break;
+        }
+    }
+    if (g_default_devices.empty()) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count < 1) count = 1;  // no device: ctx_create reports it
+        for (int k = 0; k < count && k < 64; k++) g_default_devices.push_back(k);
+    }
+    g_default_ctxs.assign(g_default_devices.size(), nullptr);
+    g_default_batches.assign(g_default_devices.size(), 0);
+}
 
 }  // namespace
 
 namespace bg {
-int default_ctx(blissgpu_ctx** out) {
+int default_ctx_count() {
     std::lock_guard<std::mutex> lk(g_default_mu);
-    if (!g_default_ctx) {
-        int rc = blissgpu_ctx_create(0, &g_default_ctx);
+    default_init_locked();
+    return (int)g_default_devices.size();
+}
+int default_ctx_at(int k, blissgpu_ctx** out) {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    default_init_locked();
+    if (k < 0 || k >= (int)g_default_devices.size()) return fail(BLISSGPU_ERR_INVALID, "default context", "no such default device");
+    if (!g_default_ctxs[k]) {
+        int rc = blissgpu_ctx_create(g_default_devices[k], &g_default_ctxs[k]);
         if (rc) return rc;
     }
-    *out = g_default_ctx;
+    *out = g_default_ctxs[k];
     return BLISSGPU_OK;
 }
+int default_ctx(blissgpu_ctx** out) { return default_ctx_at(0, out); }
+void default_ctx_count_batch(int k) {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (k >= 0 && k < (int)g_default_batches.size()) g_default_batches[k]++;
+}
 }  // namespace bg
+
+extern "C" {
+int blissgpu_default_device_count(void) { return default_ctx_count(); }
+int blissgpu_default_device(int k) {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    default_init_locked();
+    return (k >= 0 && k < (int)g_default_devices.size()) ? g_default_devices[k] : -1;
+}
+uint64_t blissgpu_default_device_batches(int k) {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    return (k >= 0 && k < (int)g_default_batches.size()) ? g_default_batches[k] : 0;
+}
+}  // extern "C"
 
 namespace {
 

@@ -171,7 +171,11 @@ struct Prof {  // HIP events around one launch, on the stream the kernel is laun
 constexpr uint32_t MAX_SONGS_PER_CHUNK = 65535;  // grid.y of the (run, song) launches
 constexpr size_t PIPELINE_MIN_CHUNK_BYTES = 512u << 20;  // a pipeline chunk below ~16 three-minute songs no longer fills the GPU
 
-int default_ctx(blissgpu_ctx** out);  // process-wide context on device 0 (created on first use)
+// process-wide default contexts, one per visible device (BLISSGPU_DEFAULT_DEVICES restricts / repeats), created on first use
+int default_ctx_count();
+int default_ctx_at(int k, blissgpu_ctx** out);
+int default_ctx(blissgpu_ctx** out);  // = default_ctx_at(0): the batch / distance / playlist forms without a context argument
+void default_ctx_count_batch(int k);  // statistics: one more coalesced batch served by default context k
 
 // scheduler.hip
 void scheduler_release(blissgpu_ctx* c);

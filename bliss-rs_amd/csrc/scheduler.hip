@@ -290,8 +290,10 @@ int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t*
     }
     const bool direct = bytes_per_sample == 4 && channels == 1;  // f32 mono: copied verbatim into the PCM buffer
     const size_t frame_bytes = (size_t)bytes_per_sample * channels;
-    // groups of <= 2 GiB of mono f32 PCM (~128 three-minute songs): large enough to fill the GPU, small enough to pipeline
-    const uint64_t group_cap = 512ull << 20;  // frames
+    // groups of <= 2 GiB of staging (mono f32: ~128 three-minute songs): large enough to fill the GPU, small enough to
+    // pipeline.  The cap is in BYTES of the wider of the two buffers of a group (raw interleaved frames / mono f32), so an
+    // 8-channel f32 batch stages 2 x 2 GiB like a mono one instead of 2 x 16 GiB.
+    const uint64_t group_cap = (2048ull << 20) / std::max<size_t>(4, frame_bytes);  // frames
     struct Group { uint32_t i0, n; std::vector<uint64_t> doff, dlen; uint64_t total; };
     std::vector<Group> groups;
     for (uint32_t i0 = 0; i0 < n_songs;) {
@@ -388,16 +390,20 @@ struct AnalyzeReq {
 };
 
 // One mutex, two condition variables: `arrive` wakes a leader that is gathering its batch, `done` wakes the callers whose
-// requests a leader has finished.  Whoever finds no batch running becomes the leader and takes the whole queue.
+// requests a leader has finished -- and the callers waiting for a free device.  There is one leader seat per default
+// context (= per visible device): whoever finds a seat free takes it and the whole queue with it, so on an 8-GPU node
+// the N worker threads of the reference's bulk path (src/song/decoder.rs:299-329) keep all eight devices busy, each
+// batch going to the device whose previous batch finished first.  The lowest free seat is taken, so a lone caller
+// always lands on the first device (whose context is warm).
 std::mutex g_mu;
 std::condition_variable g_cv_arrive, g_cv_done;
 std::vector<AnalyzeReq*> g_queue;
-bool g_running = false;
-size_t g_last_batch = 1;
+std::vector<char> g_seat_taken;
+std::vector<size_t> g_seat_last_batch;
 
-void run_batch(std::vector<AnalyzeReq*>& take, const char* who) {
+void run_batch(std::vector<AnalyzeReq*>& take, int seat, const char* who) {
     blissgpu_ctx* c = nullptr;
-    const int rc0 = default_ctx(&c);
+    const int rc0 = default_ctx_at(seat, &c);
     // one device batch per (sample format, channels, features version) class; in practice there is one class
     std::vector<char> served(take.size(), 0);
     for (size_t a = 0; a < take.size(); a++) {
@@ -427,31 +433,45 @@ void run_batch(std::vector<AnalyzeReq*>& take, const char* who) {
             if (!rc) memcpy(t->out, rows.data() + q * d, d * sizeof(float));
         }
     }
+    default_ctx_count_batch(seat);
 }
 
 int submit(AnalyzeReq& r, const char* who) {
+    const int n_seats = default_ctx_count();
     std::unique_lock<std::mutex> lk(g_mu);
+    if (g_seat_taken.empty()) { g_seat_taken.assign(n_seats, 0); g_seat_last_batch.assign(n_seats, 1); }
     g_queue.push_back(&r);
     g_cv_arrive.notify_one();
     while (!r.done) {
-        if (g_running) {
+        int seat = -1;
+        for (int k = 0; k < n_seats && seat < 0; k++)
+            if (!g_seat_taken[k]) seat = k;
+        if (seat < 0) {  // every device is running a batch: the next leader will take this request along
             g_cv_done.wait(lk);
             continue;
         }
-        g_running = true;
+        g_seat_taken[seat] = 1;
         // The callers the previous batch released are on their way back with their next song: when that batch showed
         // there is company, give them a moment (at most 200 us against a batch of milliseconds) instead of running a
         // batch of one.  A lone caller never waits.
-        if (g_last_batch > 1)
-            g_cv_arrive.wait_for(lk, std::chrono::microseconds(200), [&] { return g_queue.size() >= g_last_batch; });
+        if (g_seat_last_batch[seat] > 1)
+            g_cv_arrive.wait_for(lk, std::chrono::microseconds(200), [&] { return g_queue.size() >= g_seat_last_batch[seat]; });
         std::vector<AnalyzeReq*> take;
         take.swap(g_queue);
-        g_last_batch = take.size();
-        lk.unlock();
-        run_batch(take, who);
-        lk.lock();
-        for (AnalyzeReq* t : take) t->done = true;
-        g_running = false;
+        if (!take.empty()) {  // (empty: another leader took everything, this caller's request included, during the wait)
+            g_seat_last_batch[seat] = take.size();
+            lk.unlock();
+            // No exception may strand the followers (their `done` flags) or keep the seat: a failed allocation while
+            // gathering the batch becomes an error code on every request of the batch.
+            try {
+                run_batch(take, seat, who);
+            } catch (...) {
+                for (AnalyzeReq* t : take) { t->rc = BLISSGPU_ERR_OOM; t->err = "out of host memory while gathering the batch"; }
+            }
+            lk.lock();
+            for (AnalyzeReq* t : take) t->done = true;
+        }
+        g_seat_taken[seat] = 0;
         g_cv_done.notify_all();
     }
     lk.unlock();

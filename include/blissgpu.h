@@ -13,10 +13,13 @@
  * Threading (src/song/decoder.rs:299-329: analyze is called from up to cores + 1 worker threads): EVERY entry point
  * is re-entrant and thread-safe.  Each context carries a mutex; calls on one context are serialised (the host-pointer
  * forms hold it for the whole call, the device forms while they enqueue), calls on different contexts run
- * concurrently.  The entry points without a context argument share one process-wide context on device 0.
+ * concurrently.  The entry points without a context argument use process-wide DEFAULT contexts, one per visible HIP
+ * device (created on first use; BLISSGPU_DEFAULT_DEVICES="0,2,3" restricts / orders them).
  * Concurrent single-song calls (blissgpu_analyze / blissgpu_analyze_interleaved) are COALESCED: the calls that
- * arrive while a batch is running are analysed together as the next device batch, so N worker threads each calling
- * Song::analyze reach batch throughput without changing the caller.
+ * arrive while a device is busy are analysed together as its next batch, and a batch goes to whichever default device
+ * is free -- so N worker threads each calling Song::analyze reach batch throughput on EVERY GPU of the node without
+ * changing the caller.  The batch / distance / playlist forms without a context argument run on the first default
+ * device (blissgpu_node_* spreads a batch over the node).
  * The library has NO CPU fallback: every compute entry point fails with BLISSGPU_ERR_NO_DEVICE when no
  * gfx950 device / HIP runtime is usable.
  */
@@ -80,12 +83,19 @@ int blissgpu_ctx_set_workspace_limit(blissgpu_ctx *ctx, uint64_t bytes);
 uint64_t blissgpu_ctx_get_workspace_limit(blissgpu_ctx *ctx);
 int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
 
+/* The default contexts: how many there are, the HIP ordinal of the k-th, and how many coalesced batches of single-song
+ * calls it has served so far (load statistics). */
+int blissgpu_default_device_count(void);
+int blissgpu_default_device(int k);
+uint64_t blissgpu_default_device_batches(int k);
+
 uint32_t blissgpu_feature_count(uint32_t features_version); /* FeaturesVersion::feature_count, src/lib.rs:181-186 */
 
 /* Replaces Song::analyze / Song::analyze_with_options (src/song/mod.rs:403-508) for ONE song in host
  * memory.  Returns BLISSGPU_OK and writes feature_count floats, or BLISSGPU_OK with *status =
  * BLISSGPU_SONG_TOO_SHORT (out filled with NaN).  status may be NULL.  Uses the process-wide default
- * context on device 0; safe to call from any number of threads (concurrent calls are coalesced into one device batch). */
+ * contexts; safe to call from any number of threads (concurrent calls are coalesced into device batches, one in flight
+ * per device). */
 int blissgpu_analyze(const float *pcm, uint64_t len, uint32_t features_version, float *out, int32_t *status);
 /* Same for raw decoder output: `frames` frames of `channels` interleaved samples (BLISSGPU_SAMPLE_F32 / _S16) at
  * 22 050 Hz.  s16 is widened with sample / 32768 and channels are downmixed ON THE DEVICE exactly like the reference's

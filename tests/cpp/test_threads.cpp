@@ -129,6 +129,11 @@ int main(int argc, char** argv) {
     std::printf("serial_songs_per_sec %.1f\n", n_songs / serial_s);
     std::printf("distance_euclidean_ns %.0f\n", dist_ns);
     std::printf("distance_mahalanobis_ns %.0f\n", maha_ns);
+    // the default contexts behind the single-song front (one per visible device; BLISSGPU_DEFAULT_DEVICES repeats / restricts)
+    std::printf("default_devices %d\n", blissgpu_default_device_count());
+    for (int k = 0; k < blissgpu_default_device_count(); k++)
+        std::printf("default_device_%d_hip_ordinal %d\ndefault_device_%d_batches %llu\n", k, blissgpu_default_device(k), k,
+                    (unsigned long long)blissgpu_default_device_batches(k));
     std::printf("all checks passed\n");
     return 0;
 }

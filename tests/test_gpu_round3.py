@@ -136,3 +136,47 @@ def test_node_argument_validation(bliss):
     node.close()
     h = C.c_void_p()
     assert L.blissgpu_node_create(1, (C.c_int * 1)(99), C.byref(h)) == _ffi.ERR_NO_DEVICE
+
+
+# ---------------------------------------------------------------------------------------------
+# the single-song front on MORE THAN ONE default context (src/song/decoder.rs:299-329: N worker threads each calling
+# Song::analyze): on an 8-GPU node there is one default context per device; on the one-GPU test box two contexts on
+# device 0 stand in for two devices
+# ---------------------------------------------------------------------------------------------
+def _threads_exe(tmp_path):
+    exe = tmp_path / "test_threads"
+    libdir = os.path.join(ROOT, "bliss-rs_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_threads.cpp"),
+                           "-o", str(exe), f"-L{libdir}", "-lblissgpu", f"-Wl,-rpath,{libdir}"])
+    return exe
+
+
+def _kv(stdout):
+    return {l.split()[0]: l.split()[1] for l in stdout.splitlines() if len(l.split()) == 2}
+
+
+def test_single_song_front_spreads_over_two_default_contexts(tmp_path):
+    exe = _threads_exe(tmp_path)
+    env = dict(os.environ, BLISSGPU_DEFAULT_DEVICES="0,0")
+    out = subprocess.run([str(exe), "16", "32"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all checks passed" in out.stdout          # every threaded row bit-identical to the serial run
+    kv = _kv(out.stdout)
+    assert kv["default_devices"] == "2"
+    assert kv["default_device_0_hip_ordinal"] == "0" and kv["default_device_1_hip_ordinal"] == "0"
+    assert int(kv["default_device_0_batches"]) > 0 and int(kv["default_device_1_batches"]) > 0, out.stdout
+    print(out.stdout)
+
+
+def test_default_contexts_follow_the_visible_devices(tmp_path, bliss):
+    import torch
+    from bliss_rs_amd import _ffi
+
+    exe = _threads_exe(tmp_path)
+    out = subprocess.run([str(exe), "4", "8"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    kv = _kv(out.stdout)
+    assert int(kv["default_devices"]) == torch.cuda.device_count()
+    L = _ffi.lib()
+    assert L.blissgpu_default_device_count() == torch.cuda.device_count() and L.blissgpu_default_device(0) == 0
+    assert L.blissgpu_default_device(99) == -1
