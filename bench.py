@@ -56,6 +56,16 @@ def parse():
     ap.add_argument("--ws-limit-gb", type=float, default=0.0, help="workspace limit per chunk slot; 0 = library default")
     ap.add_argument("--host-feed-songs", type=int, default=256)
     ap.add_argument("--seed", type=int, default=20260927)
+    ap.add_argument("--serial", action="store_true", help="every kernel on one stream (clean per-kernel timings; not the production schedule)")
+    ap.add_argument("--tail-mode", type=int, default=None, help="beat tracker placement (blissgpu_ctx_set_option)")
+    ap.add_argument("--pipeline-chunks", type=int, default=None, help="cut batches into at least this many chunks")
+    ap.add_argument("--traffic", action="store_true",
+                    help="measure roofline.traffic now (two rocprofv3 --pmc passes of a 256-song batch, ~1 min) instead of "
+                         "reading profiles/hbm_traffic.json")
+    ap.add_argument("--node", type=int, default=0,
+                    help="drive N GPUs from THIS process through the C-ABI node API (blissgpu_node_*: what a Rust host "
+                         "would call) instead of one torch.distributed rank per GPU; configs batch / library")
+    ap.add_argument("--node-devices", default="", help="HIP ordinals of the node's ranks, e.g. 0,0 = two loopback ranks on one GPU")
     return ap.parse_args()
 
 
@@ -65,6 +75,18 @@ def mixed_lengths(n_total, seed):
     return rng.integers(30 * 22050, 600 * 22050 + 1, n_total).astype(np.uint64)
 
 
+def kernel_sources_sha():
+    """sha256 over the HIP sources the analysis kernels are built from (what a traffic measurement is valid for)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "bliss-rs_amd", "csrc")
+    for name in ("kernels_chroma.hip", "kernels_fft512.hip", "kernels_tempo.hip", "kernels_finalize.hip", "fft_r16.hpp",
+                 "device_utils.hpp", "internal.hpp"):
+        h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()
+
+
 def oracle_mod():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
@@ -72,38 +94,62 @@ def oracle_mod():
     return O
 
 
+def host_cpus():
+    """(physical cores, logical CPUs) of this host from /proc/cpuinfo; physical = distinct (physical id, core id) pairs"""
+    logical = os.cpu_count() or 1
+    try:
+        cores, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+        return (len(cores) or logical), logical
+    except OSError:
+        return logical, logical
+
+
 def cpu_baseline(global_indices, lengths, features_version=2):
     """The oracle (C restatement of the reference algorithm, oracle/) on the host cores: the same white-noise songs
-    (bit-identical generator), one song per thread at a time.  TIMED with the baseline-only build (oracle/Makefile
-    `native`: -O3 -march=native, vectorisable radix-4 FFT, compiled on this machine) at two thread counts -- the port is
-    memory-bound well before it runs out of cores -- and the better one is reported with the thread count it used; the
-    parity CHECK of the GPU rows uses the default build (the pinned checker), timed too for reference.  This is a PORT
-    (kind: "port"), not bliss-rs itself: see DESIGN.md section 5 for what that does and does not say."""
+    (bit-identical generator), one song per thread at a time (the reference's bulk path runs one Song::analyze per worker
+    thread, src/song/decoder.rs:282-329).  TIMED with the baseline-only build (oracle/Makefile `native`: -O3
+    -march=native, vectorisable radix-4 FFT, compiled on this machine) over a SWEEP of thread counts up to the logical
+    CPU count -- the best one is the value, `cores` is the thread count it used, and the host's physical cores / logical
+    CPUs are stated separately; the parity CHECK of the GPU rows uses the default build (the pinned checker), timed too.
+    This is a PORT (kind: "port"), not bliss-rs itself: see DESIGN.md section 5 for what that does and does not say."""
     O = oracle_mod()
-    ncpu = os.cpu_count() or 1
+    physical, ncpu = host_cpus()
     n = len(global_indices)
     pcm = np.concatenate([O.white_noise(int(g), int(l)) for g, l in zip(global_indices, lengths)])
     lens = np.asarray(lengths, np.uint64)
     offs = np.zeros(n, np.uint64)
     offs[1:] = np.cumsum(lens)[:-1]
     t0 = time.perf_counter()
-    out, status = O.song_analyze_batch(pcm, offs, lens, features_version, min(ncpu, n, 32))
+    out, status = O.song_analyze_batch(pcm, offs, lens, features_version, min(ncpu, n, 64))
     checker_rate = n / (time.perf_counter() - t0)
     tried, fast_note = [], "baseline-only build (-O3 -march=native, radix-4 FFT)"
     try:
-        for cores in sorted({min(ncpu, n, 32), min(ncpu, n, 64)}):
+        for cores in sorted({min(ncpu, n, c) for c in (32, 64, 128, 256, physical)}):
             t0 = time.perf_counter()
             fast, _ = O.song_analyze_batch(pcm, offs, lens, features_version, cores, fast=True)
             tried.append((n / (time.perf_counter() - t0), cores))
         fast_dev = float(np.abs(fast - out).max())
     except Exception as e:  # noqa: BLE001  (no compiler on the box: fall back to the checker's own timing, say so)
-        tried, fast_note, fast_dev = [(checker_rate, min(ncpu, n, 32))], f"default build only ({type(e).__name__})", None
+        tried, fast_note, fast_dev = [(checker_rate, min(ncpu, n, 64))], f"default build only ({type(e).__name__})", None
     rate, cores = max(tried)
     res = {"value": round(rate, 3), "unit": "songs/sec", "cores": cores, "kind": "port",
-           "sample": f"{n} of the same white-noise songs ({int(lens.sum())} samples), oracle/bliss_oracle.c, {fast_note} -- an "
-                     "oracle port, not bliss-rs (rustfft is SIMD mixed-radix); "
-                     + ", ".join(f"{c} threads: {r:.1f} songs/s" for r, c in tried) + f" ({ncpu} logical CPUs); "
-                     f"default (checker) build: {checker_rate:.1f} songs/s",
+           "host_physical_cores": physical, "host_logical_cpus": ncpu,
+           "threads_sweep": {str(c): round(r, 2) for r, c in sorted(tried, key=lambda rc: rc[1])},
+           "sample": f"{n} of the same white-noise songs ({int(lens.sum())} samples; spread over the whole batch), "
+                     f"oracle/bliss_oracle.c, {fast_note} -- an oracle port, not bliss-rs (rustfft is SIMD mixed-radix); one "
+                     f"song per thread, best of the thread-count sweep (threads_sweep) on a host with {physical} physical "
+                     f"cores / {ncpu} logical CPUs; default (checker) build: {checker_rate:.1f} songs/s",
            "samples_per_sec": round(rate * float(lens.mean()), 1),
            "max_abs_dev_baseline_build_vs_checker": fast_dev}
     try:  # per-descriptor seconds of ONE song on one core (SURVEY.md 8d): where the CPU time goes
@@ -144,8 +190,92 @@ def small_calls():
     return res
 
 
+def main_node(args):
+    """--node N: the C-ABI node form (blissgpu_node_*: one host process, N devices, ONE ncclAllGather of the feature rows
+    inside the library) -- what a Rust / C host calls.  torch only allocates the per-device PCM buffers here."""
+    import torch
+
+    import bliss_rs_amd as bliss
+
+    world = args.node
+    devices = [int(x) for x in args.node_devices.split(",")] if args.node_devices else list(range(world))
+    if len(devices) != world:
+        raise SystemExit("--node-devices must name --node ordinals")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the library has no CPU path")
+    node = bliss.Node(world, devices=devices)
+    loopback = len(set(devices)) < world
+    N = args.samples
+    if args.config == "library":
+        n_total, version, scaling = (args.songs * world) if args.songs else 10000, 1, "strong"
+        all_lens = np.full(n_total, N, np.uint64)
+        workload = (f"configs[2]: {n_total} pre-decoded {N}-sample (3-min) songs sharded across {world} GPU(s), all-gather of "
+                    f"the 20-dim feature rows (FeaturesVersion 1)")
+    elif args.config == "batch":
+        per = args.songs or 1024
+        n_total, version, scaling = per * world, 2, "weak"
+        all_lens = np.full(n_total, N, np.uint64)
+        workload = (f"configs[1]: batch of {per} synthetic {N}-sample (3-min) white-noise f32 PCM buffers per GPU, full "
+                    f"23-feature descriptor set (FeaturesVersion 2)")
+    else:
+        raise SystemExit("--node supports --config batch / library")
+    d = 23 if version == 2 else 20
+    ranks = node.shard(all_lens)
+    offs = np.zeros(n_total, np.uint64)
+    bufs = []
+    for r in range(world):
+        mine = np.flatnonzero(ranks == r)
+        padded = (all_lens[mine] + np.uint64(63)) // np.uint64(64) * np.uint64(64)
+        o = np.zeros(len(mine), np.uint64)
+        o[1:] = np.cumsum(padded)[:-1]
+        offs[mine] = o
+        buf = torch.empty(int(padded.sum()) + 64, dtype=torch.float32, device=f"cuda:{devices[r]}")
+        node.synth_white_noise(r, buf.data_ptr(), o, all_lens[mine], mine)
+        bufs.append(buf)
+        if loopback or args.ws_limit_gb > 0:
+            node.ctx_set_workspace_limit(r, int((args.ws_limit_gb if args.ws_limit_gb > 0 else 8.0) * (1 << 30)))
+    ptrs = [b.data_ptr() for b in bufs]
+
+    def step():
+        node.analyze_device(ptrs, offs, all_lens, ranks, version)   # enqueues every rank, gathers, synchronises
+
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = time.perf_counter() - t0
+    rows = node.features(0)
+    total_samples = float(all_lens.sum())
+    algo = 4.0 * total_samples + 4.0 * d * n_total
+    result = {
+        "metric": "songs/sec (3-min 22 050 Hz f32) at 1/2/4/8 GPU; HBM GB/s vs roofline",
+        "value": round(n_total * args.steps / elapsed, 2), "unit": "songs/sec", "n_gpus": len(set(devices)), "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic white noise (Philox4x32-10, uniform [-0.5,0.5)), generated in HBM",
+        "config": {"workload": workload, "name": args.config, "songs_total": n_total, "samples_per_song": N, "features": d,
+                   "ranks": world, "devices": devices,
+                   "parallelism": f"ONE process, C-ABI node API (blissgpu_node_analyze_device): songs sharded x{world}, "
+                                  + ("loopback ranks on shared GPUs: gather by device-to-device copies" if loopback
+                                     else "one grouped ncclAllGather of the feature rows over xGMI")},
+        "whole_job_GBps": round(algo * args.steps / elapsed / 1e9, 2),
+        "rows_finite": bool(np.isfinite(rows).all()),
+        "note": "per-kernel roofline and cpu_baseline are reported by the one-rank-per-GPU form (bench.py --gpus N)",
+    }
+    if args.config == "library" and not args.no_pairwise:
+        t0 = time.perf_counter()
+        D = node.pairwise("euclidean")
+        result["node_pairwise"] = {"n": n_total, "ms_including_D2H_of_the_matrix": round((time.perf_counter() - t0) * 1e3, 1),
+                                   "symmetric": bool(np.array_equal(D, D.T))}
+    print(json.dumps(result))
+    node.close()
+
+
 def main():
     args = parse()
+    if args.node > 0:
+        return main_node(args)
     import torch
     import torch.distributed as dist
 
@@ -165,6 +295,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     ctx = bliss.Context(local_rank)
+    if args.serial:
+        ctx.set_option("serial", 1)
+    if args.tail_mode is not None:
+        ctx.set_option("tail_mode", args.tail_mode)
+    if args.pipeline_chunks is not None:
+        ctx.set_option("pipeline_chunks", args.pipeline_chunks)
     version = 2
     scaling = "weak"
     notes = {}
@@ -254,13 +390,21 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ctx.profile_enable(True)
-    ctx.profile_reset()
+    # the timed region: exactly --steps steps, no per-kernel events inside it
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full = step()
     fence()
     elapsed = time.perf_counter() - t0
+    # the same steps again with HIP events around every launch (on the stream each kernel runs on): the kernel durations of
+    # the roofline.  Kept out of the timed region: the events cost a few microseconds per launch.
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    t0p = time.perf_counter()
+    for _ in range(args.steps):
+        full = step()
+    fence()
+    elapsed_profiled = time.perf_counter() - t0p
     prof = ctx.profile()
     ctx.profile_enable(False)
     chunks = ctx.last_chunks()
@@ -290,17 +434,37 @@ def main():
                     "algorithmic_bytes_per_launch": algo_bytes,
                     "whole_step_GBps": round(algo_bytes_step / (elapsed / args.steps) / 1e9, 2),
                     "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
+                    "kernel_durations_from": f"{args.steps} steps run right after the timed region with HIP events around every "
+                                             f"launch ({elapsed_profiled / args.steps * 1e3:.3f} ms per step with the events)",
                     "note": "by operation count the path is FP32-vector/LDS bound (roofline_fp32); see DESIGN.md section 3"}
-        traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(traffic_file):
+        # HBM bytes of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, tests/tools/hbm_traffic.sh).  The
+        # counters cannot be read from inside the process they profile, so the figure comes from profiles/hbm_traffic.json
+        # -- which records the hash of the kernel sources it was measured on and is REFUSED when they have changed since --
+        # or, with --traffic, is measured now by running the PMC passes on this box.
+        if args.traffic:
+            try:
+                subprocess.run(["bash", os.path.join(ROOT, "tests", "tools", "hbm_traffic.sh")], cwd=ROOT, timeout=900,
+                               capture_output=True, env=dict(os.environ, SONGS="256", TRAFFIC_OUT=os.path.join(ROOT, "gpurun_out", "hbm")))
+            except Exception as e:  # noqa: BLE001
+                roofline["traffic_source"] = f"--traffic failed: {type(e).__name__}"
+        for traffic_file, label in ((os.path.join(ROOT, "gpurun_out", "hbm", "hbm_traffic.json") if args.traffic else "", "measured in this run"),
+                                    (os.path.join(ROOT, "profiles", "hbm_traffic.json"), "profiles/hbm_traffic.json")):
+            if not traffic_file or not os.path.exists(traffic_file) or roofline["traffic"] is not None:
+                continue
             try:
                 tf = json.load(open(traffic_file))
-                if tf.get("kernel") == dom and tf.get("bytes_per_sample"):
-                    roofline["traffic"] = tf["bytes_per_sample"] * total_samples / launches_per_step
-                elif tf.get("kernel") == dom and tf.get("songs_per_launch") and args.config != "mixed":
+                now = kernel_sources_sha()
+                if tf.get("kernel_sources_sha256") != now:
+                    roofline["traffic_source"] = (f"{label} REFUSED: measured on kernel sources {str(tf.get('kernel_sources_sha256'))[:12]}, "
+                                                  f"this build is {now[:12]} (re-run tests/tools/hbm_traffic.sh)")
+                    continue
+                if tf.get("kernel") == dom and tf.get("songs_per_launch") and args.config != "mixed":
                     roofline["traffic"] = tf["bytes_per_launch"] * (n / launches_per_step / tf["songs_per_launch"])
-            except Exception:
-                pass
+                    roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / algo_bytes, 3)
+                    roofline["traffic_source"] = (f"{label}@{now[:12]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
+                                                  f"{tf['songs_per_launch']} songs per launch, scaled by songs; FETCH_SIZE x2 (gfx950), KiB -> bytes")
+            except Exception as e:  # noqa: BLE001
+                roofline["traffic_source"] = f"{label}: {type(e).__name__}"
         flops_step = FLOP_PER_SAMPLE * total_samples
         fp32 = {"bound": "fp32-vector", "flops": flops_step, "achieved": round(flops_step / (elapsed / args.steps) / 1e12, 3),
                 "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
@@ -339,12 +503,19 @@ def main():
                 order = np.argsort(lens)
                 picks = sorted({int(order[int(q * (n - 1))]) for q in np.linspace(0.0, 1.0, 16)})
             else:
-                picks = list(range(min(args.cpu_songs, n)))
+                # spread over the whole launch grid (not the first songs of it): every n / cpu_songs-th song
+                k = min(args.cpu_songs, n)
+                picks = [int(i) for i in np.linspace(0, n - 1, k).round().astype(int)]
             cb, ref = cpu_baseline(global_idx[picks], lens[picks], version)
             got = out[picks].cpu().numpy()
             err = np.abs(got - ref)
             cb["checked_songs"] = len(picks)
+            cb["checked_song_indices"] = f"{picks[0]}..{picks[-1]} ({len(picks)} songs spread evenly over the {n} of the batch)"
             cb["max_abs_err_vs_gpu_non_tempo"] = float(err[:, 1:].max())
+            # tempo against the reference's own tolerance (1e-5, src/song/mod.rs:582-590), as a histogram
+            cb["tempo_abs_err"] = {"over_1e-5": int((err[:, 0] > 1e-5).sum()), "over_3e-5": int((err[:, 0] > 3e-5).sum()),
+                                   "over_1e-4": int((err[:, 0] > 1e-4).sum()), "max": float(err[:, 0].max()),
+                                   "songs_over_1e-5": [int(picks[i]) for i in np.flatnonzero(err[:, 0] > 1e-5)][:32]}
             cb["tempo_mismatches"] = int((err[:, 0] > 1e-4).sum())
             return cb
 

@@ -15,6 +15,7 @@ OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_NAN, ERR_RCCL = 0, 1, 2, 3
 SAMPLE_F32, SAMPLE_S16 = 0, 1
 SONG_OK, SONG_TOO_SHORT = 0, 1
 METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_MAHALANOBIS = 0, 1, 2
+OPT_SERIAL, OPT_TAIL_MODE, OPT_PIPELINE_CHUNKS, OPT_CAND_BUDGET = 0, 1, 2, 3
 
 _f32p = C.POINTER(C.c_float)
 _f64p = C.POINTER(C.c_double)
@@ -34,6 +35,7 @@ SIGNATURES = {
     "blissgpu_ctx_set_workspace_limit": (C.c_int, [_vp, C.c_uint64]),
     "blissgpu_ctx_get_workspace_limit": (C.c_uint64, [_vp]),
     "blissgpu_ctx_synchronize": (C.c_int, [_vp]),
+    "blissgpu_ctx_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
     "blissgpu_default_device_count": (C.c_int, []),
     "blissgpu_default_device": (C.c_int, [C.c_int]),
     "blissgpu_default_device_batches": (C.c_uint64, [C.c_int]),

@@ -207,21 +207,12 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
     // instead of queueing behind the thousands of workgroups of an FFT kernel
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    int prio_aux = prio_greatest;
-    if (const char* e = getenv("BLISSGPU_SIDE_PRIORITY")) {  // developer aid: 0 = both normal, 2 = only the tuning stream high
-        if (atoi(e) == 0) prio_greatest = prio_aux = prio_least;
-        if (atoi(e) == 2) prio_aux = prio_least;
-    }
+    const int prio_aux = prio_greatest;
     se = hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio_aux);
     if (se == hipSuccess) se = hipStreamCreateWithPriority(&c->chr_stream, hipStreamNonBlocking, prio_greatest);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_interop, hipEventDisableTiming);
     if (se == hipSuccess) se = hipHostMalloc((void**)&c->h_scalar, 64, hipHostMallocDefault);
     if (se != hipSuccess) { blissgpu_ctx_destroy(c); return fail(BLISSGPU_ERR_HIP, "aux stream/events", hipGetErrorString(se)); }
-    if (const char* e = getenv("BLISSGPU_SERIAL")) c->serial = (e[0] == '1');
-    if (const char* e = getenv("BLISSGPU_TAIL_MODE")) c->tail_mode = atoi(e);
-    if (const char* e = getenv("BLISSGPU_PIPELINE_CHUNKS")) c->pipeline_chunks = (uint32_t)std::min(64, std::max(1, atoi(e)));
-    // developer / test aid: slots per chroma frame of the tuning-candidate pool (0 forces the re-scan path of tune_final_kernel)
-    if (const char* e = getenv("BLISSGPU_CAND_BUDGET")) c->cand_budget = (uint32_t)std::max(0, atoi(e));
     // Scratch limit per chunk slot: a third of what is free now, at most 64 GiB (1024 three-minute songs need ~37 GB).  A
     // batch that needs more runs as several chunks; a chunk that still does not fit (the caller allocated in the meantime)
     // is halved until it does.
@@ -284,6 +275,21 @@ int blissgpu_ctx_signal_stream(blissgpu_ctx* c, void* consumer_stream) {
     if ((hipStream_t)consumer_stream == c->stream) return BLISSGPU_OK;
     HIP_TRY(hipEventRecord(c->ev_interop, c->stream));
     HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, c->ev_interop, 0));
+    return BLISSGPU_OK;
+}
+
+int blissgpu_ctx_set_option(blissgpu_ctx* c, int option, int64_t value) {
+    if (!c) return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_set_option", "ctx is NULL");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // nothing of the previous schedule is in flight when it changes
+    switch (option) {
+        case BLISSGPU_OPT_SERIAL: c->serial = value != 0; break;
+        case BLISSGPU_OPT_TAIL_MODE: c->tail_mode = (int)value; break;
+        case BLISSGPU_OPT_PIPELINE_CHUNKS: c->pipeline_chunks = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); break;
+        case BLISSGPU_OPT_CAND_BUDGET: c->cand_budget = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 714)); break;
+        default: return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_set_option", "unknown option");
+    }
     return BLISSGPU_OK;
 }
 

@@ -108,11 +108,11 @@ struct blissgpu_ctx {
     hipStream_t aux_stream = nullptr;  // per-song tails: PCM statistics, summaries, beat tracker, row assembly
     hipStream_t chr_stream = nullptr;  // tuning estimate of a chunk, beside the next chunk's FFT kernels
     int tail_mode = -1;                // beat tracker: -1 = beside the FFT-8192 kernel unless the batch is one chunk, 0 / 1 force
-                                       // beside / behind it (BLISSGPU_TAIL_MODE, developer aid)
-    uint32_t pipeline_chunks = 1;      // cut big batches into at least this many chunks (BLISSGPU_PIPELINE_CHUNKS; measured: the
+                                       // beside / behind it (BLISSGPU_OPT_TAIL_MODE)
+    uint32_t pipeline_chunks = 1;      // cut big batches into at least this many chunks (BLISSGPU_OPT_PIPELINE_CHUNKS; measured: the
                                        // per-song tails have a fixed latency per launch, so more chunks than memory needs lose)
     hipEvent_t ev_interop = nullptr;
-    bool serial = false;               // BLISSGPU_SERIAL=1: single stream (clean per-kernel timings)
+    bool serial = false;               // BLISSGPU_OPT_SERIAL: single stream (clean per-kernel timings)
     uint64_t ws_limit = 0;             // bytes per chunk slot (set from the free device memory at creation)
     uint32_t cand_budget = bg::CAND_BUDGET_PER_FRAME;  // tuning-candidate pool: slots per chroma frame of a chunk
     // tables

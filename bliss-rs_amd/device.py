@@ -58,6 +58,13 @@ class Context:
     def synchronize(self):
         _ffi.check(self._L.blissgpu_ctx_synchronize(self._h))
 
+    OPTIONS = {"serial": _ffi.OPT_SERIAL, "tail_mode": _ffi.OPT_TAIL_MODE, "pipeline_chunks": _ffi.OPT_PIPELINE_CHUNKS,
+               "cand_budget": _ffi.OPT_CAND_BUDGET}
+
+    def set_option(self, name: str, value: int):
+        """Scheduling knobs for the measurement tools and the tests (blissgpu_ctx_set_option)."""
+        _ffi.check(self._L.blissgpu_ctx_set_option(self._h, self.OPTIONS[name], int(value)))
+
     def set_workspace_limit(self, nbytes: int):
         """Scratch bytes of ONE chunk slot; larger batches stream through the two slots in length-bucketed chunks."""
         _ffi.check(self._L.blissgpu_ctx_set_workspace_limit(self._h, nbytes))
@@ -274,6 +281,20 @@ class Node:
             self._h = None
 
     __del__ = close
+
+    def synth_white_noise(self, rank: int, d_pcm_ptr: int, offsets, lengths, song_index):
+        """Benchmark input on `rank`'s device: song i (at d_pcm_ptr + offsets[i]) gets generator index song_index[i]."""
+        offsets, lengths = _u64(offsets), _u64(lengths)
+        idx = np.ascontiguousarray(song_index, np.uint32)
+        ctx = self._L.blissgpu_node_ctx(self._h, rank)
+        _ffi.check(self._L.blissgpu_synth_white_noise_indexed_device(
+            ctx, C.c_void_p(int(d_pcm_ptr)), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+            lengths.ctypes.data_as(C.POINTER(C.c_uint64)), idx.ctypes.data_as(C.POINTER(C.c_uint32)), len(offsets)))
+        _ffi.check(self._L.blissgpu_ctx_synchronize(ctx))
+
+    def ctx_set_workspace_limit(self, rank: int, nbytes: int):
+        """Scratch bytes of one chunk slot of `rank`'s context (several loopback ranks share one GPU's memory)."""
+        _ffi.check(self._L.blissgpu_ctx_set_workspace_limit(self._L.blissgpu_node_ctx(self._h, rank), nbytes))
 
     def shard(self, lengths) -> np.ndarray:
         lengths = _u64(lengths)

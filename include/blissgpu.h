@@ -82,6 +82,13 @@ int blissgpu_ctx_signal_stream(blissgpu_ctx *ctx, void *consumer_stream);
 int blissgpu_ctx_set_workspace_limit(blissgpu_ctx *ctx, uint64_t bytes);
 uint64_t blissgpu_ctx_get_workspace_limit(blissgpu_ctx *ctx);
 int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
+/* Scheduling knobs of ONE context for the measurement tools and the tests (the library reads no environment variable for
+ * them; defaults are what production uses).  Synchronises the context's stream. */
+#define BLISSGPU_OPT_SERIAL 0           /* 1: every kernel on one stream, nothing overlaps (clean per-kernel timings) */
+#define BLISSGPU_OPT_TAIL_MODE 1        /* beat tracker: -1 auto (default), 0 beside / 1 behind the FFT-8192 kernel */
+#define BLISSGPU_OPT_PIPELINE_CHUNKS 2  /* cut big batches into at least this many chunks (default 1) */
+#define BLISSGPU_OPT_CAND_BUDGET 3      /* tuning-candidate pool: slots per chroma frame (default 48; 0 starves the pool) */
+int blissgpu_ctx_set_option(blissgpu_ctx *ctx, int option, int64_t value);
 
 /* The default contexts: how many there are, the HIP ordinal of the k-th, and how many coalesced batches of single-song
  * calls it has served so far (load statistics). */

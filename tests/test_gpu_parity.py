@@ -6,16 +6,20 @@ Tolerances (features are normalised to [-1, 1]):
   * integer work (zero crossings, statuses, pitch histogram bins, beat counts): exact
   * distances: bit-exact (the kernel reproduces ndarray's summation order)
   * the 22 non-tempo features: |gpu - oracle| <= FEATURE_TOL = 1e-5, the reference's own tolerance (observed <= 5e-6); the only
-    difference between the two paths is f32 FFT rounding (radix-4 Stockham + real split on the GPU,
+    difference between the two paths is f32 FFT rounding (three register radix-16 passes + real split on the GPU,
     radix-2 c2c in the oracle, rustfft in the reference -- no two of them round alike).  Rolloff is a
     per-frame integer bin, so one frame flipping by one bin moves its mean by 43.07 Hz / n_frames:
     the rolloff entries get ROLLOFF_FLIPS such flips on top.
-  * tempo: the beat tracker is a chain of argmax / threshold decisions; a flipped decision is not an
-    error of degree.  Songs whose tempo differs by more than TEMPO_TOL = 1e-4 are COUNTED and reported.
+  * tempo: held to the reference's own 1e-5 (src/song/mod.rs:582-590) for a RECORDED fraction of the songs, every song
+    above it listed, and to TEMPO_HARD = 1e-4 for every song.  The fraction is not a convenience: the tempo value ends in
+    a parabolic interpolation of an autocorrelation peak that amplifies FFT rounding, and the oracle ITSELF moves by
+    more than 1e-5 on 15 of the 1024 bench songs when its FFTs run in f64 instead of f32 (max 5.8e-5); the GPU differs
+    from the f32 oracle on 16 of 1024 (max 4.3e-5) and from the f64 oracle on 14 (profiles/r03_full_check_1024songs.json,
+    tests/tools/full_check.py --noise-floor).  No f32 implementation, rustfft included, can be held under that floor.
   * tuning (discrete, 0.01 semitone bins): must match for every song of the battery; a mismatch would
     be reported, not hidden (white noise makes the histogram argmax a near-tie by construction).
-  * tempo mismatches are held to a RECORDED expectation (EXPECTED_TEMPO_MISMATCHES = 0 on every battery), not to a
-    percentage: a regression cannot hide inside an allowance.
+  * tempo differences above TEMPO_HARD are held to a RECORDED expectation (EXPECTED_TEMPO_MISMATCHES = 0 everywhere): a
+    flipped beat decision cannot hide inside the allowance for rounding.
 """
 import os
 
@@ -27,7 +31,9 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 FEATURE_TOL = 1e-5   # the reference's own tolerance (src/song/mod.rs:582-590); observed <= 5e-6
-TEMPO_TOL = 1e-4
+TEMPO_TOL = 1e-5      # the reference's tolerance; held for >= 1 - TEMPO_NOISE_FRACTION of the songs of a test
+TEMPO_HARD = 1e-4     # every song
+TEMPO_NOISE_FRACTION = 0.03   # recorded: 1.6 % of the 1024 bench songs (GPU vs oracle), 1.5 % oracle-f32 vs oracle-f64
 ROLLOFF_FLIPS = 2     # frames whose rolloff bin may differ by one (observed: 0 on the battery)
 EXPECTED_TEMPO_MISMATCHES = 0   # recorded expectation: a change here is a regression to look at, not noise to absorb
 N3MIN = 3969000
@@ -64,12 +70,22 @@ def _run(ctx, songs, version=2):
 
 def _tol(n_samples, d):
     tol = np.full(d, FEATURE_TOL)
-    tol[0] = TEMPO_TOL
+    tol[0] = TEMPO_HARD
     n_t = (n_samples - 512) // 128 + 1
     flip = 2.0 * (22050.0 / 512.0) / 11025.0 / n_t
     tol[4] += ROLLOFF_FLIPS * flip                                   # mean rolloff
     tol[5] += ROLLOFF_FLIPS * flip * np.sqrt(max(n_t, 1)) * 0.5      # its std moves ~ bin / sqrt(n)
     return tol
+
+
+def _tempo_gate(errs, names):
+    """tempo |gpu - oracle| of the songs of one test: all <= TEMPO_HARD, and <= TEMPO_TOL (the reference's 1e-5) for all
+    but the recorded noise fraction (at least one song); every song above 1e-5 is listed in the test output"""
+    errs = np.asarray(errs, np.float64)
+    over = [(names[i], float(errs[i])) for i in np.flatnonzero(errs > TEMPO_TOL)]
+    print(f"tempo: {len(errs) - len(over)} of {len(errs)} songs within 1e-5; above it: {over}")
+    assert int((errs > TEMPO_HARD).sum()) == EXPECTED_TEMPO_MISMATCHES, over
+    assert len(over) <= max(1, int(np.ceil(TEMPO_NOISE_FRACTION * len(errs)))), over
 
 
 def battery(oracle):
@@ -129,7 +145,7 @@ def test_battery_vs_oracle(ctx, oracle, version):
     got, status = _run(ctx, [songs[k] for k in names], version)
     tuning, n_bpms = ctx.last_tuning(len(names))
     assert (status == 0).all()
-    tempo_mismatch, report = [], []
+    report, tempo_err = [], []
     for i, k in enumerate(names):
         ref = oracle.song_analyze(songs[k], version)
         _, otuning = oracle.chroma_desc(songs[k])
@@ -138,12 +154,10 @@ def test_battery_vs_oracle(ctx, oracle, version):
         report.append(f"{k:26s} max|err| non-tempo {err[1:].max():.2e} tempo {err[0]:.2e} tuning {tuning[i]:+.2f}/{otuning:+.2f}")
         assert abs(tuning[i] - otuning) < 1e-12, f"{k}: tuning gpu {tuning[i]} oracle {otuning}"
         assert (err[1:] <= tol[1:]).all(), f"{k}: {err}"
-        if err[0] > tol[0]:
-            tempo_mismatch.append((k, float(got[i][0]), float(ref[0])))
+        tempo_err.append(err[0])
         assert n_bpms[i] == len(oracle.BPMDesc().run(songs[k]).bpms()) or err[0] > tol[0]
     print("\n".join(report))
-    print("tempo mismatches:", tempo_mismatch)
-    assert len(tempo_mismatch) == EXPECTED_TEMPO_MISMATCHES, tempo_mismatch
+    _tempo_gate(tempo_err, names)
 
 
 def musical_battery(oracle):
@@ -194,7 +208,7 @@ def test_musical_battery_vs_oracle(ctx, oracle):
     got, status = _run(ctx, [songs[k] for k in names], 2)
     tuning, n_bpms = ctx.last_tuning(len(names))
     assert (status == 0).all()
-    tempo_mismatch, report, tunings = [], [], set()
+    tempo_err, report, tunings = [], [], set()
     for i, k in enumerate(names):
         ref = oracle.song_analyze(songs[k], 2)
         _, otuning = oracle.chroma_desc(songs[k])
@@ -203,13 +217,11 @@ def test_musical_battery_vs_oracle(ctx, oracle):
         report.append(f"{k:26s} max|err| non-tempo {err[1:].max():.2e} tempo {err[0]:.2e} tuning {tuning[i]:+.2f}/{otuning:+.2f} bpms {n_bpms[i]}")
         assert abs(tuning[i] - otuning) < 1e-12, f"{k}: tuning gpu {tuning[i]} oracle {otuning}"
         assert (err[1:] <= tol[1:]).all(), f"{k}: {err}"
-        if err[0] > tol[0]:
-            tempo_mismatch.append((k, float(got[i][0]), float(ref[0])))
+        tempo_err.append(err[0])
         tunings.add(round(float(tuning[i]), 2))
     print("\n".join(report))
-    print("tempo mismatches:", tempo_mismatch)
     assert len(tunings) >= 4, tunings            # the battery does exercise several filter banks
-    assert len(tempo_mismatch) == EXPECTED_TEMPO_MISMATCHES, tempo_mismatch
+    _tempo_gate(tempo_err, names)
 
 
 def test_stage_taps_vs_oracle(ctx, oracle, golden_pcm):
@@ -309,16 +321,15 @@ def test_frame_and_tile_boundary_lengths(ctx, oracle):
     got, status = _run(ctx, songs)
     tuning, n_bpms = ctx.last_tuning(len(songs))
     assert (status == 0).all()
-    bad_tempo = []
+    tempo_err = []
     for i, (n, x) in enumerate(zip(lengths, songs)):
         ref = oracle.song_analyze(x)
         _, otuning = oracle.chroma_desc(x)
         err = np.abs(got[i] - ref)
         assert abs(tuning[i] - otuning) < 1e-12, (n, tuning[i], otuning)
         assert (err[1:] <= _tol(n, 23)[1:]).all(), (n, err)
-        if err[0] > TEMPO_TOL:
-            bad_tempo.append((n, float(got[i][0]), float(ref[0])))
-    assert len(bad_tempo) == EXPECTED_TEMPO_MISMATCHES, bad_tempo
+        tempo_err.append(err[0])
+    _tempo_gate(tempo_err, lengths)
 
 
 def test_mixed_duration_corpus_and_cue_slices(bliss, oracle):
@@ -349,7 +360,7 @@ def test_mixed_duration_corpus_and_cue_slices(bliss, oracle):
         ref = oracle.song_analyze(oracle.white_noise(500 + i, int(lens[i])))
         tol = _tol(int(lens[i]), 23)
         assert (np.abs(out[i][1:] - ref[1:]) <= tol[1:]).all(), i
-        assert abs(out[i][0] - ref[0]) <= TEMPO_TOL, i
+        assert abs(out[i][0] - ref[0]) <= TEMPO_HARD, i
         one, _ = alone.analyze(pcm, offs[i:i + 1], lens[i:i + 1], 2)
         alone.synchronize()
         assert np.array_equal(one.cpu().numpy()[0], out[i])   # chunk / batch composition does not matter
@@ -387,16 +398,16 @@ def test_full_size_properties(ctx, oracle):
     ctx.synchronize()
     got = out.cpu().numpy()
     assert (status.cpu().numpy() == 0).all() and np.isfinite(got).all()
-    tempo_bad = 0
+    tempo_err = []
     for i in (0, 7, 23):
         x = oracle.white_noise(100 + i, N)
         assert np.array_equal(pcm[i * N:(i + 1) * N].cpu().numpy(), x)
         ref = oracle.song_analyze(x)
         err = np.abs(got[i] - ref)
         assert (err[1:] <= _tol(N, 23)[1:]).all(), err
-        tempo_bad += err[0] > TEMPO_TOL
+        tempo_err.append(err[0])
         assert got[i][1] == np.float32(2.0 * np.float32(oracle.number_crossings(x)) / np.float32(N) - 1.0)
-    assert tempo_bad == 0
+    _tempo_gate(tempo_err, [0, 7, 23])
     half = pcm * 0.5
     out2, _ = ctx.analyze(half, offs, lens, 2)
     ctx.synchronize()

@@ -121,11 +121,8 @@ def test_candidate_pool_exhaustion_takes_the_exact_path(bliss, oracle):
     base = bliss.Context(0)
     ref, _ = _run(base, songs)
     ref_tuning, _ = base.last_tuning(len(songs))
-    os.environ["BLISSGPU_CAND_BUDGET"] = "0"     # read at context creation: a 64-slot pool for the whole chunk
-    try:
-        starved = bliss.Context(0)
-    finally:
-        del os.environ["BLISSGPU_CAND_BUDGET"]
+    starved = bliss.Context(0)
+    starved.set_option("cand_budget", 0)          # a 64-slot pool for the whole chunk
     got, _ = _run(starved, songs)
     tuning, _ = starved.last_tuning(len(songs))
     assert np.array_equal(tuning, ref_tuning)

@@ -180,3 +180,186 @@ def test_default_contexts_follow_the_visible_devices(tmp_path, bliss):
     L = _ffi.lib()
     assert L.blissgpu_default_device_count() == torch.cuda.device_count() and L.blissgpu_default_device(0) == 0
     assert L.blissgpu_default_device(99) == -1
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[4] and configs[2] at the size ONE GPU owns on the 8-GPU node
+# ---------------------------------------------------------------------------------------------
+def _config4_lengths(n_total=50000, seed=20260927):
+    """bench.py's mixed_lengths: durations uniform 30 s - 10 min at 22 050 Hz, one seeded draw for the whole corpus"""
+    rng = np.random.default_rng(seed)
+    return rng.integers(30 * 22050, 600 * 22050 + 1, n_total).astype(np.uint64)
+
+
+def _tol(n_samples, d, tempo_tol):
+    tol = np.full(d, FEATURE_TOL)
+    tol[0] = tempo_tol
+    n_t = (n_samples - 512) // 128 + 1
+    flip = 2.0 * (22050.0 / 512.0) / 11025.0 / n_t      # one rolloff bin of one frame (a per-frame integer decision)
+    tol[4] += 2 * flip
+    tol[5] += 2 * flip * np.sqrt(max(n_t, 1)) * 0.5
+    return tol
+
+
+def _oracle_rows(oracle, picks, gen_index, lens, version):
+    """oracle rows of the picked songs, a few host threads (ctypes releases the GIL)"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(i):
+        return oracle.song_analyze(oracle.white_noise(int(gen_index[i]), int(lens[i])), version)
+
+    with ThreadPoolExecutor(max_workers=min(16, len(picks))) as ex:
+        return np.stack(list(ex.map(one, picks)))
+
+
+def test_config4_one_gpu_share_full_count(bliss, oracle):
+    """configs[4]: rank 0's share of the 50 000-song 30 s - 10 min corpus under the 8-rank plan -- ~6 250 songs, ~174 GB
+    of PCM resident, length-bucketed chunks streamed through the two workspace slots.  Checks that do not need 6 250
+    oracle runs: run-to-run determinism, bit-identity under another chunking and with songs analysed alone, exact ZCR;
+    plus the oracle on 16 songs spread from the shortest to the longest bucket."""
+    import torch
+    from bliss_rs_amd.shard import shard_plan
+
+    torch.cuda.empty_cache()
+    all_lens = _config4_lengths()
+    ranks = shard_plan(all_lens, 8)
+    global_idx = np.flatnonzero(ranks == 0)
+    lens = all_lens[global_idx]
+    n = len(lens)
+    assert 6000 < n < 6500
+    padded = (lens + np.uint64(63)) // np.uint64(64) * np.uint64(64)
+    offs = np.zeros(n, np.uint64)
+    offs[1:] = np.cumsum(padded)[:-1]
+    pcm_bytes = int(padded.sum()) * 4
+    slot = 24 << 30
+    free_b, _ = torch.cuda.mem_get_info()
+    assert free_b > pcm_bytes + 2 * slot * 1.15 + (6 << 30), f"{free_b / 2**30:.0f} GiB free: the full share does not fit"
+    c = bliss.Context(0)
+    c.set_workspace_limit(slot)
+    pcm = torch.empty(int(padded.sum()) + 64, dtype=torch.float32, device="cuda")
+    c.synth_white_noise(pcm, offs, lens, song_index=global_idx)
+    out, status = c.analyze(pcm, offs, lens, 2)
+    c.synchronize()
+    got = out.cpu().numpy()
+    chunks = c.last_chunks()
+    assert (status.cpu().numpy() == 0).all() and np.isfinite(got).all()
+    assert chunks >= 8, chunks                                   # ~37 MB of workspace per three-minute equivalent
+    # run-to-run determinism of the whole share
+    out2, _ = c.analyze(pcm, offs, lens, 2)
+    c.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), got)
+    # another chunking (half the slot: about twice the chunks) -- bit-identical
+    c.set_workspace_limit(slot // 2)
+    out3, _ = c.analyze(pcm, offs, lens, 2)
+    c.synchronize()
+    assert c.last_chunks() > chunks
+    assert np.array_equal(out3.cpu().numpy(), got)
+    # 16 songs spread over the length buckets (shortest ... longest of the share): alone, and against the oracle
+    order = np.argsort(lens, kind="stable")
+    picks = order[np.linspace(0, n - 1, 16).astype(int)]
+    alone, st = c.analyze(pcm, offs[picks], lens[picks], 2)
+    c.synchronize()
+    assert np.array_equal(alone.cpu().numpy(), got[picks])
+    ref = _oracle_rows(oracle, picks, global_idx, lens, 2)
+    listed = []
+    for k, i in enumerate(picks):
+        x_n = int(lens[i])
+        err = np.abs(got[i] - ref[k])
+        assert (err[1:] <= _tol(x_n, 23, 1.0)[1:]).all(), (int(i), x_n, err)
+        if err[0] > 1e-5:
+            listed.append((int(global_idx[i]), x_n, float(err[0])))
+        assert err[0] <= 1e-4, (int(i), x_n, float(err[0]))
+        # exact ZCR from the resident PCM
+        x = pcm[int(offs[i]):int(offs[i]) + x_n].cpu().numpy()
+        assert got[i][1] == np.float32(2.0 * np.float32(oracle.number_crossings(x)) / np.float32(x_n) - 1.0)
+    # tempo at the reference's own 1e-5 (src/song/mod.rs:582-590): every song above it is listed, and there may be at
+    # most one among the 16 (DESIGN.md section 4: the measured fraction and the f32-FFT noise floor)
+    print("tempo over 1e-5:", listed)
+    assert len(listed) <= 1, listed
+    c.close()
+    del pcm
+    torch.cuda.empty_cache()
+
+
+def test_config2_one_gpu_share_full_count_through_the_node_api(bliss, oracle):
+    """configs[2] at full count: a 10 000-song library on an 8-rank node, 20-dim rows (FeaturesVersion 1), the padded
+    gather of 8 x 1 250 rows, the scatter to 10 000 global rows and the row-block pairwise (1 250 x 10 000 per rank).
+    The test box has one GPU: the 8 ranks are loopback contexts on it and the library is 8 references to each of 1 250
+    resident three-minute songs (19.8 GB of PCM, one GPU's share), so every rank analyses a full 1 250-song share."""
+    import torch
+    from bliss_rs_amd.shard import shard_plan
+
+    torch.cuda.empty_cache()
+    N, share, world = 3969000, 1250, 8
+    n_total = share * world
+    offs1 = np.arange(share, dtype=np.uint64) * np.uint64(N)
+    lens1 = np.full(share, N, np.uint64)
+    c = bliss.Context(0)
+    c.set_workspace_limit(8 << 30)
+    pcm = torch.empty(share * N + 64, dtype=torch.float32, device="cuda")
+    c.synth_white_noise(pcm, offs1, lens1, first_song_index=0)
+    ref_rows, st = c.analyze(pcm, offs1, lens1, 1)
+    c.synchronize()
+    ref_rows = ref_rows.cpu().numpy()
+    assert (st.cpu().numpy() == 0).all() and ref_rows.shape == (share, 20)
+    # the library: song i is resident song i % share
+    offs = np.tile(offs1, world)
+    lens = np.tile(lens1, world)
+    ranks = shard_plan(lens, world)
+    assert np.array_equal(ranks, np.arange(n_total) % world)        # equal lengths: round-robin, 1 250 each
+    node = bliss.Node(world, devices=[0] * world)
+    for r in range(world):
+        node.ctx_set_workspace_limit(r, 6 << 30)
+    node.analyze_device([pcm.data_ptr()] * world, offs, lens, ranks, 1)
+    want = np.tile(ref_rows, (world, 1))
+    for r in range(world):
+        assert np.array_equal(node.features(r), want), r          # eight contexts, every row bit-identical
+    # oracle on 16 songs of the share
+    picks = np.linspace(0, share - 1, 16).astype(int)
+    ref = _oracle_rows(oracle, picks, np.arange(share), lens1, 1)
+    over = []
+    for k, i in enumerate(picks):
+        err = np.abs(ref_rows[i] - ref[k])
+        assert (err[1:] <= _tol(N, 20, 1.0)[1:]).all(), (int(i), err)
+        assert err[0] <= 1e-4
+        if err[0] > 1e-5:
+            over.append((int(i), float(err[0])))
+    assert len(over) <= 1, over
+    # row-block pairwise over the 8 ranks = the one-context matrix of the 1 250 songs, tiled 8 x 8
+    D = node.pairwise("euclidean")
+    D0 = c.pairwise(torch.from_numpy(ref_rows).cuda(), torch.from_numpy(ref_rows).cuda(), "euclidean").cpu().numpy()
+    assert D.shape == (n_total, n_total)
+    for bi in range(world):
+        for bj in range(world):
+            assert np.array_equal(D[bi * share:(bi + 1) * share, bj * share:(bj + 1) * share], D0), (bi, bj)
+    assert (np.diag(D) == 0).all() and np.array_equal(D, D.T)
+    node.close()
+    c.close()
+    del pcm
+    torch.cuda.empty_cache()
+
+
+def test_more_than_65535_songs_in_one_batch(bliss, oracle):
+    """70 000 one-second clips fit one chunk's workspace; the beat tracker's (run, song) grid does not address that many
+    songs, so the planner closes a chunk at 65 535 songs."""
+    import torch
+
+    n, N = 70000, 22050
+    c = bliss.Context(0)
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(22080)       # 64-sample aligned songs
+    lens = np.full(n, N, np.uint64)
+    pcm = torch.empty(n * 22080 + 64, dtype=torch.float32, device="cuda")
+    c.synth_white_noise(pcm, offs, lens, first_song_index=5000)
+    out, status = c.analyze(pcm, offs, lens, 2)
+    c.synchronize()
+    got = out.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all() and np.isfinite(got).all()
+    assert c.last_chunks() >= 2
+    picks = np.array([0, 1, 65534, 65535, 65536, 69999])
+    alone, _ = c.analyze(pcm, offs[picks], lens[picks], 2)
+    c.synchronize()
+    assert np.array_equal(alone.cpu().numpy(), got[picks])
+    ref = oracle.song_analyze(oracle.white_noise(5000 + 65535, N))
+    err = np.abs(got[65535] - ref)
+    assert (err[1:] <= _tol(N, 23, 1.0)[1:]).all() and err[0] <= 1e-4, err
+    c.close()

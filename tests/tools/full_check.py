@@ -2,7 +2,12 @@
 """Tool-side (not bench) parity check of EVERY song of the default bench batch: the 1024 synthetic 3-minute songs of
 configs[1] analysed on the GPU against the CPU oracle (all host cores, ~40 s).  Prints one JSON line.
 
-    python tests/tools/full_check.py [--songs 1024] [--threads 64]
+    python tests/tools/full_check.py [--songs 1024] [--threads 64] [--noise-floor]
+
+Tempo is reported as a per-song error HISTOGRAM (counts over 1e-5 -- the reference's tolerance, src/song/mod.rs:582-590 --
+3e-5 and 1e-4, every song over 1e-5 listed).  --noise-floor repeats the oracle with its FFTs in f64 (bo_set_fft_double)
+and reports the same histogram for oracle(f32 FFT) against oracle(f64 FFT): what FFT rounding alone does to the tempo
+value on these songs, i.e. the floor no f32 implementation (rustfft included) can be held under.
 """
 import argparse
 import json
@@ -21,6 +26,7 @@ def main():
     ap.add_argument("--songs", type=int, default=1024)
     ap.add_argument("--samples", type=int, default=3969000)
     ap.add_argument("--threads", type=int, default=64)
+    ap.add_argument("--noise-floor", action="store_true")
     args = ap.parse_args()
     import torch
 
@@ -38,17 +44,39 @@ def main():
     got = out.cpu().numpy()
     tuning, _ = ctx.last_tuning(n)
     t0 = time.perf_counter()
-    ref = np.empty((n, 23), np.float32)
-    step = 128  # bounded host memory: 128 songs = 2 GB of PCM at a time
-    for i0 in range(0, n, step):
-        k = min(step, n - i0)
-        host = pcm[i0 * N:(i0 + k) * N].cpu().numpy()
-        r, st = O.song_analyze_batch(host, np.arange(k, dtype=np.uint64) * np.uint64(N), np.full(k, N, np.uint64), 2,
-                                     min(args.threads, k))
-        assert (st == 0).all()
-        ref[i0:i0 + k] = r
+
+    def oracle_rows():
+        ref = np.empty((n, 23), np.float32)
+        step = 128  # bounded host memory: 128 songs = 2 GB of PCM at a time
+        for i0 in range(0, n, step):
+            k = min(step, n - i0)
+            host = pcm[i0 * N:(i0 + k) * N].cpu().numpy()
+            r, st = O.song_analyze_batch(host, np.arange(k, dtype=np.uint64) * np.uint64(N), np.full(k, N, np.uint64), 2,
+                                         min(args.threads, k))
+            assert (st == 0).all()
+            ref[i0:i0 + k] = r
+        return ref
+
+    def tempo_histogram(e):
+        over = np.flatnonzero(e > 1e-5)
+        return {"songs": int(len(e)), "over_1e-5": int((e > 1e-5).sum()), "over_3e-5": int((e > 3e-5).sum()),
+                "over_1e-4": int((e > 1e-4).sum()), "max": float(e.max()),
+                "fraction_within_1e-5": round(float((e <= 1e-5).mean()), 6),
+                "songs_over_1e-5": [{"song": int(i), "abs_err": float(e[i])} for i in over[:64]]}
+
+    ref = oracle_rows()
     err = np.abs(got - ref)
+    noise = None
+    if args.noise_floor:
+        O.set_fft_double(True)
+        ref64 = oracle_rows()
+        O.set_fft_double(False)
+        e64 = np.abs(ref.astype(np.float64) - ref64.astype(np.float64))
+        noise = {"what": "oracle with f32 FFTs against the same oracle with f64 FFTs (bo_set_fft_double), same songs",
+                 "tempo": tempo_histogram(e64[:, 0]), "max_abs_err_non_tempo": float(e64[:, 1:].max()),
+                 "gpu_vs_f64_oracle_tempo": tempo_histogram(np.abs(got.astype(np.float64) - ref64)[:, 0])}
     res = {"songs": n, "samples_per_song": N, "oracle_seconds": round(time.perf_counter() - t0, 1),
+           "tempo_gpu_vs_oracle": tempo_histogram(err[:, 0]), "tempo_noise_floor": noise,
            "max_abs_err_non_tempo": float(err[:, 1:].max()),
            "max_abs_err_per_feature": [float(x) for x in err.max(axis=0)],
            "songs_over_1e-5_non_tempo": int((err[:, 1:].max(axis=1) > 1e-5).sum()),

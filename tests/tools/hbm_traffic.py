@@ -48,4 +48,16 @@ name = os.environ.get("DOMINANT", "bg::stft8192_kernel")
 if name in rows:
     tot["kernel"] = name.replace("bg::", "")
     tot["bytes_per_launch"] = rows[name]["read_bytes"] + rows[name]["write_bytes"]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+try:  # what the measurement is valid for: bench.py refuses the file when the kernel sources have changed since
+    import hashlib
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "bliss-rs_amd", "csrc")
+    h = hashlib.sha256()
+    for name in ("kernels_chroma.hip", "kernels_fft512.hip", "kernels_tempo.hip", "kernels_finalize.hip", "fft_r16.hpp",
+                 "device_utils.hpp", "internal.hpp"):
+        h.update(open(os.path.join(csrc, name), "rb").read())
+    tot["kernel_sources_sha256"] = h.hexdigest()
+except OSError:
+    pass
 json.dump(tot, open(os.path.join(root, "hbm_traffic.json"), "w"), indent=1)

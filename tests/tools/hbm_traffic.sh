@@ -1,9 +1,11 @@
 #!/bin/bash
 # HBM traffic of every analysis kernel: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit
 # one pass on gfx950), kernel-trace only.  usage (GPU box): SONGS=256 bash tests/tools/hbm_traffic.sh
-R=$PWD; cd /tmp; export TMPDIR=/tmp; export BLISSGPU_SERIAL=1
+R=$PWD; cd /tmp; export TMPDIR=/tmp; export KBENCH_SERIAL=1
 S=${SONGS:-256}
-B="python $R/bench.py --songs $S --steps 1 --warmup 1 --no-cpu-baseline --no-pairwise --no-host-feed --no-small-calls"
+# the batch is driven by tests/tools/kbench (C ABI, no Python: nothing but the library's kernels in the trace)
+[ -x $R/tests/tools/kbench ] || g++ -std=c++17 -O1 -o $R/tests/tools/kbench $R/tests/tools/kbench.cpp -ldl
+B="$R/tests/tools/kbench $R/bliss-rs_amd/libblissgpu.so $S 180 1"
 rm -rf $R/gpurun_out/hbm
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do

@@ -2,8 +2,8 @@
 // work on the GPU box (a fresh box pays 1-2 minutes for its first `import torch`; this pays nothing).
 //   build: g++ -std=c++17 -O1 -o tests/tools/kbench tests/tools/kbench.cpp -ldl
 //   usage: kbench <libblissgpu.so> [songs=256] [seconds=180] [steps=3] [ragged=0]
-// Prints ms per kernel per step (HIP events on the stream each kernel runs on; set BLISSGPU_SERIAL=1 for every kernel
-// alone), the step's wall time, and an FNV-1a hash of the feature rows (two builds that agree bit for bit print the same hash).
+// Prints ms per kernel per step (HIP events on the stream each kernel runs on; KBENCH_SERIAL=1 for every kernel alone,
+// KBENCH_TAIL_MODE / KBENCH_PIPELINE_CHUNKS set the other scheduling options), the step's wall time, and an FNV-1a hash of the feature rows (two builds that agree bit for bit print the same hash).
 #include <dlfcn.h>
 
 #include <chrono>
@@ -29,9 +29,12 @@ int main(int argc, char** argv) {
     SYM(blissgpu_last_error) SYM(blissgpu_ctx_create) SYM(blissgpu_ctx_destroy) SYM(blissgpu_malloc) SYM(blissgpu_free)
     SYM(blissgpu_synth_white_noise_device) SYM(blissgpu_analyze_batch_device) SYM(blissgpu_ctx_synchronize)
     SYM(blissgpu_profile_enable) SYM(blissgpu_profile_reset) SYM(blissgpu_profile_kernel_count) SYM(blissgpu_profile_kernel_name)
-    SYM(blissgpu_profile_get) SYM(blissgpu_memcpy_d2h)
+    SYM(blissgpu_profile_get) SYM(blissgpu_memcpy_d2h) SYM(blissgpu_ctx_set_option)
     blissgpu_ctx* c = nullptr;
     OK(p_blissgpu_ctx_create(0, &c));
+    if (const char* e = std::getenv("KBENCH_SERIAL")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_SERIAL, std::atoi(e)));
+    if (const char* e = std::getenv("KBENCH_TAIL_MODE")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_TAIL_MODE, std::atoi(e)));
+    if (const char* e = std::getenv("KBENCH_PIPELINE_CHUNKS")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_PIPELINE_CHUNKS, std::atoi(e)));
     std::vector<uint64_t> offs(n), lens(n);
     uint64_t total = 0;
     for (uint32_t i = 0; i < n; i++) {
