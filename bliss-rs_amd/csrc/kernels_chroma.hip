@@ -246,6 +246,7 @@ __device__ __forceinline__ uint32_t peak_record(uint32_t coarse, int pitch_bin_o
 // Z[4096-k] for the real-input split.  The window (read once per workgroup) stays in registers.
 // ------------------------------------------------------------------------------------------------
 constexpr int STFT_FRAMES_PER_WG = STFT_TILE;
+constexpr int STFT_GROUP = 4;     // workgroups that share a super-tile of STFT_GROUP * STFT_TILE frames, one frame in four each
 constexpr int LHIST_BINS = 512;  // 16 octaves of 32 coarse bins
 constexpr int EX1_PITCH = 257;   // k1-major rows of 256 (+1): the 16 lanes of a ds_read2_b64 group tile all 32 banks
 constexpr int EX2_PITCH = 272;   // j1-major rows of 256 (+16): shifts odd rows by 32 banks
@@ -274,6 +275,9 @@ __device__ __forceinline__ long reflect_index(long p, long n) {
     return p;
 }
 
+#ifndef STFT_STORE_AUX
+#define STFT_STORE_AUX 2
+#endif
 // 4 workgroups per CU: 128 VGPRs, spill-free
 __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restrict__ pcm,
                                                        const SongDesc* __restrict__ songs, uint32_t n_songs,
@@ -282,7 +286,8 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
                                                        const float2* __restrict__ tw,
                                                        float* __restrict__ spec,
                                                        float* __restrict__ frame_max, uint32_t* __restrict__ h1,
-                                                       uint32_t* __restrict__ peak_rec, uint32_t* __restrict__ peak_cnt) {
+                                                       uint32_t* __restrict__ peak_rec, uint32_t* __restrict__ peak_cnt,
+                                                       uint32_t n_tiles) {
     __shared__ f2 lds[STFT_LDS];
     __shared__ float red[4];
     // peaks are first counted in an LDS window of the coarse-magnitude histogram (a frame's peaks lie
@@ -297,9 +302,21 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         const float2 a = tw[32 * (((threadIdx.x >> 4) * (threadIdx.x & 15)) & 255)];
         tw256[threadIdx.x] = mk(a.x, a.y);
     }
-    const uint32_t s = find_segment(pfx_c, n_songs, blockIdx.x);
+    // Which frames a workgroup owns is chosen for the L2.  Consecutive frames share 5 987 of their 8 192 samples; a
+    // workgroup walking 16 CONSECUTIVE frames re-reads them one frame period later, by when the 128 workgroups of its XCD
+    // have streamed their own 32 KB windows through the 4 MiB L2 -- the PCM was fetched 2.2 times.  Instead the FOUR
+    // workgroups of a 64-frame super-tile take every fourth frame each (member m: frames 64 s + m, + 4, + 8, ...) and sit
+    // on the SAME XCD (blocks b, b + 8, b + 16, b + 24: dispatch puts block b on XCD b % 8), so the four frames being
+    // loaded at any time overlap and a sample's 3.7 readers arrive within a fraction of a frame period.  A workgroup's
+    // own consecutive frames (4 hops = 8 820 samples apart) no longer overlap at all.  Placement is a matter of speed
+    // only: any block -> XCD map gives the same results.
+    const uint32_t bx = blockIdx.x;
+    const uint32_t wg = (bx & ~31u) | ((bx & 7u) << 2) | ((bx >> 3) & 3u);  // logical tile of this block
+    if (wg >= n_tiles) return;                                             // grid padded to a multiple of 32
+    const uint32_t s = find_segment(pfx_c, n_songs, wg);
     const SongDesc sd = songs[s];
-    const uint32_t tile = blockIdx.x - pfx_c[s];
+    const uint32_t tile = wg - pfx_c[s];                                   // 4 x super-tile + member
+    const uint32_t f_first = (tile >> 2) * (uint32_t)(STFT_GROUP * STFT_FRAMES_PER_WG) + (tile & 3u);
     const float* __restrict__ x = pcm + sd.pcm_off;
     const int t = threadIdx.x;
     const long n = (long)sd.n;
@@ -365,14 +382,14 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
     // The window multiply (the first use of the prefetched samples, i.e. the vmcnt wait) sits at the END of the
     // loop body: there every path has issued the loads followed by the stores, so the wait is "all but the
     // stores"; at the loop head the prologue path (no stores) would force a full vmcnt(0) drain per frame.
-    if (tile * STFT_FRAMES_PER_WG < sd.n_c) {
-        load_frame(tile * STFT_FRAMES_PER_WG, v);
+    if (f_first < sd.n_c) {
+        load_frame(f_first, v);
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window (src/utils.rs:37-39, :49)
     }
 #pragma unroll 1
     for (int fi = 0; fi < STFT_FRAMES_PER_WG; fi++) {
-        const uint32_t f = tile * STFT_FRAMES_PER_WG + fi;
+        const uint32_t f = f_first + (uint32_t)(STFT_GROUP * fi);
         if (f >= sd.n_c) break;  // uniform
         // ---- pass 1: DFT over n1 at n2 = t = 16 m1 + m2; twiddle W_256^(m1 k1) ----
         radix16(v);
@@ -424,8 +441,8 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
             m_mid = mag_from_sq(split_one_sq(v[R16(8)], v[R16(8)], mk(0.0f, -1.0f)));  // k = 2048: W_8192^2048 = -i
             mx = fmaxf(mx, m_mid);
         }
-        const bool has_next = fi + 1 < STFT_FRAMES_PER_WG && f + 1 < sd.n_c;  // uniform
-        if (has_next) load_frame(f + 1, v);
+        const bool has_next = fi + 1 < STFT_FRAMES_PER_WG && f + STFT_GROUP < sd.n_c;  // uniform
+        if (has_next) load_frame(f + STFT_GROUP, v);
         mx = wave_max_dpp(mx);
         // The split only reads the UPPER half of the exchange buffer (complex slots 2049..4095 = bytes 16 392..32 767);
         // the row of 4128 magnitudes goes into the dead lower half (words 0..4095) and, for bin 4096 and the zero padding,
@@ -461,7 +478,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
                 const int q = t + 256 * i;
                 if (i < 4 || q < CBINS_PAD / 4) {
                     const u32x4_t val = i < 4 ? mags4[q] : mags4[q - 1024 + MAGS_TOP / 4];
-                    __builtin_amdgcn_raw_buffer_store_b128(val, r_row, 16u * (uint32_t)q, 0, 2);  // nt: streamed once
+                    __builtin_amdgcn_raw_buffer_store_b128(val, r_row, 16u * (uint32_t)q, 0, STFT_STORE_AUX);  // nt: streamed once
                 }
             }
         }
@@ -553,8 +570,8 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
 
 void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.tiles_c == 0) return;
-    hipLaunchKernelGGL(stft8192_kernel, dim3(b.tiles_c), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_c, t.hann8192,
-                       t.tw8192, w.spec, w.frame_max, w.h1, w.peak_rec, w.peak_cnt);
+    hipLaunchKernelGGL(stft8192_kernel, dim3((b.tiles_c + 31u) & ~31u), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_c,
+                       t.hann8192, t.tw8192, w.spec, w.frame_max, w.h1, w.peak_rec, w.peak_cnt, b.tiles_c);
 }
 
 // ------------------------------------------------------------------------------------------------

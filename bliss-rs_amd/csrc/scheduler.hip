@@ -128,7 +128,8 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
             t.max_runs = std::max(t.max_runs, d.n_b / BT_STEP + 1);
         }
         pfx_f[i + 1] = pfx_f[i] + (d.ok ? (d.n_f + F512_TILE - 1) / F512_TILE : 0);
-        pfx_c[i + 1] = pfx_c[i] + (d.ok ? (d.n_c + STFT_TILE - 1) / STFT_TILE : 0);
+        // FFT-8192 workgroups: four per 64-frame super-tile (they interleave its frames, see stft8192_kernel)
+        pfx_c[i + 1] = pfx_c[i] + (d.ok ? 4 * ((d.n_c + 4 * STFT_TILE - 1) / (4 * STFT_TILE)) : 0);
         pfx_ct[i + 1] = pfx_ct[i] + (d.ok ? (d.n_c + CH_TILE - 1) / CH_TILE : 0);
         pfx_cw[i + 1] = pfx_cw[i] + (d.ok ? (d.n_c + 4 * CH_TILE - 1) / (4 * CH_TILE) : 0);
     }
