@@ -275,6 +275,26 @@ __device__ __forceinline__ long reflect_index(long p, long n) {
     return p;
 }
 
+// Developer build (-DSTFT_TRACE): wall-clock shader cycles of wave 0 of every workgroup between the marks in the frame
+// loop, summed per mark over the launches (LDS counters, flushed once per workgroup); tests/tools/kbench prints the table.
+#ifdef STFT_TRACE
+__device__ unsigned long long g_stft_trace[32];
+#define TRACE_DECL __shared__ uint32_t trace_acc[32]; uint32_t trace_prev = 0;
+#define TRACE_INIT() do { if (threadIdx.x < 32) trace_acc[threadIdx.x] = 0; } while (0)
+#define TRACE_START() do { trace_prev = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#define TRACE(k) do { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&trace_acc[k], now_ - trace_prev); trace_prev = now_; } while (0)
+#define TRACE_FLUSH() do { __syncthreads(); if (threadIdx.x < 32 && trace_acc[threadIdx.x]) atomicAdd(&g_stft_trace[threadIdx.x], (unsigned long long)trace_acc[threadIdx.x]); } while (0)
+#else
+#define TRACE_DECL
+#define TRACE_INIT() do {} while (0)
+#define TRACE_START() do {} while (0)
+#define TRACE(k) do {} while (0)
+#define TRACE_FLUSH() do {} while (0)
+#endif
+
+#ifndef STFT_STORE_POS
+#define STFT_STORE_POS 0
+#endif
 #ifndef STFT_STORE_AUX
 #define STFT_STORE_AUX 2
 #endif
@@ -298,6 +318,8 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
     __shared__ uint16_t peak_list[PIP_MAX_PER_FRAME + 2];
     __shared__ uint32_t peak_count;
     __shared__ f2 tw256[256];  // W_256^(m2*j1) at [16 j1 + m2] (pass-2 twiddles, broadcast reads)
+    TRACE_DECL
+    TRACE_INIT();
     {
         const float2 a = tw[32 * (((threadIdx.x >> 4) * (threadIdx.x & 15)) & 255)];
         tw256[threadIdx.x] = mk(a.x, a.y);
@@ -387,6 +409,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window (src/utils.rs:37-39, :49)
     }
+    TRACE_START();
 #pragma unroll 1
     for (int fi = 0; fi < STFT_FRAMES_PER_WG; fi++) {
         const uint32_t f = f_first + (uint32_t)(STFT_GROUP * fi);
@@ -398,7 +421,9 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
             v[R16(k1)] = cmul_pk(v[R16(k1)], tw256[16 * k1 + hi4]);
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) lds[k1 * EX1_PITCH + t] = v[R16(k1)];
+        TRACE(0);
         __syncthreads();
+        TRACE(1);
         // ---- pass 2: thread (k1 = lo4, m2 = hi4): DFT over m1; twiddle W_4096^(m2 k1) * W_256^(m2 j1) ----
 #pragma unroll
         for (int m1 = 0; m1 < 16; m1++) v[m1] = lds[lo4 * EX1_PITCH + 16 * m1 + hi4];
@@ -406,19 +431,27 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         v[R16(0)] = cmul_pk(v[R16(0)], c_p2);
 #pragma unroll
         for (int j1 = 1; j1 < 16; j1++) v[R16(j1)] = cmul_pk(v[R16(j1)], cmul_pk(tw256[16 * j1 + hi4], c_p2));
+        TRACE(2);
         __syncthreads();
+        TRACE(3);
 #pragma unroll
         for (int j1 = 0; j1 < 16; j1++) lds[j1 * EX2_PITCH + t] = v[R16(j1)];  // = j1*272 + m2*16 + k1
+        TRACE(4);
         __syncthreads();
+        TRACE(5);
         // ---- pass 3: thread (k1 = lo4, j1 = hi4): DFT over m2 -> Z[t + 256*j2] ----
 #pragma unroll
         for (int m2 = 0; m2 < 16; m2++) v[m2] = lds[hi4 * EX2_PITCH + 16 * m2 + lo4];
         radix16(v);
+        TRACE(6);
         __syncthreads();
+        TRACE(7);
         // only the upper half (bins 2049..4095, the mirrors of this workgroup's bins 1..2047) is ever read back
 #pragma unroll
         for (int j2 = 8; j2 < 16; j2++) lds[t + 256 * j2] = v[R16(j2)];
+        TRACE(8);
         __syncthreads();
+        TRACE(9);
         // ---- real-input split + magnitude (src/utils.rs:60).  Z[k] and Z[4096-k] yield X[k] AND X[4096-k]:
         // thread t pairs its bins k = t + 256 j, j < 8, with their mirrors (k = 0 pairs DC with Nyquist);
         // bin 2048 (its own mirror) is done by thread 0 ----
@@ -465,11 +498,13 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
             if (lane_id() == 0) red[slot] = mx;
         }
         if (t == 0) peak_count = 0;
+        TRACE(10);
         __syncthreads();
+        TRACE(11);
         // The spectrogram row goes to HBM from the LDS copy as 16-byte stores (5 per thread instead of 18 scalar
         // ones).  They are issued BEHIND the next frame's loads: vmcnt retires in order, so the wait for those
         // loads at the end of the iteration is "all but the stores" and never waits for an HBM write acknowledge.
-        {
+        auto store_row = [&]() {
             const __amdgpu_buffer_rsrc_t r_row = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(spec + (sd.c_off + f) * (size_t)CBINS_PAD), 0, CBINS_PAD * 4, 0x00020000);
             const u32x4_t* mags4 = reinterpret_cast<const u32x4_t*>(lds);
@@ -481,7 +516,8 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
                     __builtin_amdgcn_raw_buffer_store_b128(val, r_row, 16u * (uint32_t)q, 0, STFT_STORE_AUX);  // nt: streamed once
                 }
             }
-        }
+        };
+        if (STFT_STORE_POS == 0) store_row();
         mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         if (t == 0) frame_max[sd.c_off + f] = mx;
         if (!have_base) {  // uniform: anchor the LDS window LHIST_BINS/2 bins below the first frame's maximum
@@ -492,6 +528,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
             have_base = true;
             __syncthreads();
         }
+        TRACE(12);
         const uint32_t lbase = lhist_base;
         // The peak phase is a chain of LDS round trips with little arithmetic between them, the transform passes are long
         // runs of arithmetic: a wavefront in the peak phase gets the issue slot first, so its few instructions never queue
@@ -532,7 +569,10 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
 #pragma unroll
             for (int j = 0; j < 6; j++)
                 if ((hits >> j) & 1u) peak_list[pos++] = (uint16_t)(t + 256 * j);
+            if (STFT_STORE_POS == 1) store_row();
+            TRACE(13);
             __syncthreads();
+            TRACE(14);
             const uint32_t n_peaks = peak_count;
             uint32_t* __restrict__ recs = peak_rec + (sd.c_off + f) * (size_t)PIP_MAX_PER_FRAME;
             if (t == 0) peak_cnt[sd.c_off + f] = n_peaks;
@@ -550,15 +590,20 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
                 else atomicAdd(&hist[b], 1u);
             }
         }
+        if (STFT_STORE_POS == 2) store_row();
         __builtin_amdgcn_s_setprio(0);
+        if (STFT_STORE_POS == 3) store_row();
         if (has_next) {
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window of the next frame
         }
+        TRACE(15);
         // mags (lds) is reused by the next frame.  (Moving this barrier behind the next frame's register-only pass-1
         // arithmetic, so that early waves do not idle here, costs 12 spilled VGPRs at 128 -- measured slower.)
         __syncthreads();
+        TRACE(16);
     }
+    TRACE_FLUSH();
     if (have_base) {
         const uint32_t lbase = lhist_base;
         for (int i = t; i < LHIST_BINS; i += 256) {
@@ -567,6 +612,17 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         }
     }
 }
+
+#ifdef STFT_TRACE
+extern "C" int blissgpu_debug_stft_trace(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stft_trace), sizeof(g_stft_trace)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stft_trace), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.tiles_c == 0) return;
