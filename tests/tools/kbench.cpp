@@ -2,6 +2,7 @@
 // work on the GPU box (a fresh box pays 1-2 minutes for its first `import torch`; this pays nothing).
 //   build: g++ -std=c++17 -O1 -o tests/tools/kbench tests/tools/kbench.cpp -ldl
 //   usage: kbench <libblissgpu.so> [songs=256] [seconds=180] [steps=3] [ragged=0]
+//          kbench <libblissgpu.so> pairwise [n=100000] [reps=3]      the n x n euclidean matrix, self (A == B) and general
 // Prints ms per kernel per step (HIP events on the stream each kernel runs on; KBENCH_SERIAL=1 for every kernel alone,
 // KBENCH_TAIL_MODE / KBENCH_PIPELINE_CHUNKS set the other scheduling options), the step's wall time, and an FNV-1a hash of the feature rows (two builds that agree bit for bit print the same hash).
 #include <dlfcn.h>
@@ -22,6 +23,34 @@ int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: kbench <lib> [songs] [seconds] [steps] [ragged]\n"); return 2; }
     void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
     if (!h) { std::fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+    if (argc > 2 && std::strcmp(argv[2], "pairwise") == 0) {
+        const uint64_t m = argc > 3 ? (uint64_t)std::atoll(argv[3]) : 100000;
+        const int reps = argc > 4 ? std::atoi(argv[4]) : 3;
+        SYM(blissgpu_last_error) SYM(blissgpu_ctx_create) SYM(blissgpu_ctx_destroy) SYM(blissgpu_malloc) SYM(blissgpu_free)
+        SYM(blissgpu_memcpy_h2d) SYM(blissgpu_pairwise_device) SYM(blissgpu_ctx_synchronize)
+        blissgpu_ctx* c = nullptr;
+        OK(p_blissgpu_ctx_create(0, &c));
+        std::vector<float> h(m * 23);
+        uint32_t s = 1234567u;
+        for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (float)(s >> 8) * (2.0f / 16777216.0f) - 1.0f; }
+        float *dA = nullptr, *dB = nullptr, *dD = nullptr;
+        OK(p_blissgpu_malloc((void**)&dA, m * 23 * 4)); OK(p_blissgpu_malloc((void**)&dB, m * 23 * 4)); OK(p_blissgpu_malloc((void**)&dD, m * m * 4));
+        OK(p_blissgpu_memcpy_h2d(c, dA, h.data(), m * 23 * 4)); OK(p_blissgpu_memcpy_h2d(c, dB, h.data(), m * 23 * 4));
+        for (int general = 0; general < 2; general++) {
+            const float* rhs = general ? dB : dA;
+            OK(p_blissgpu_pairwise_device(c, dA, m, rhs, m, 23, BLISSGPU_METRIC_EUCLIDEAN, nullptr, dD, m));
+            OK(p_blissgpu_ctx_synchronize(c));
+            auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < reps; r++) OK(p_blissgpu_pairwise_device(c, dA, m, rhs, m, 23, BLISSGPU_METRIC_EUCLIDEAN, nullptr, dD, m));
+            OK(p_blissgpu_ctx_synchronize(c));
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+            std::printf("pairwise %s n=%llu ms=%.3f pairs_per_s=%.4g GBps=%.0f\n", general ? "general(A!=B)" : "self(A==B)",
+                        (unsigned long long)m, ms, (double)m * m / (ms * 1e-3), (4.0 * m * m + 8.0 * 23 * m) / (ms * 1e-3) / 1e9);
+        }
+        p_blissgpu_free(dA); p_blissgpu_free(dB); p_blissgpu_free(dD);
+        p_blissgpu_ctx_destroy(c);
+        return 0;
+    }
     const uint32_t n = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 256;
     const double seconds = argc > 3 ? std::atof(argv[3]) : 180.0;
     const int steps = argc > 4 ? std::atoi(argv[4]) : 3;
