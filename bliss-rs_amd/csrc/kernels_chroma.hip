@@ -42,7 +42,11 @@ __global__ __launch_bounds__(256) void chroma_bank_kernel(double* __restrict__ b
     if (k >= BANK_PITCH) return;
     double* out = bank + (size_t)slot * BANK_ROWS * BANK_PITCH;
     if (k >= CBINS) {
+#ifdef HP_CHECK_A
+        for (int r = 0; r < BANK_ROWS; r++) out[(size_t)r * BANK_PITCH + k] = (double)(r * 8192 + k);
+#else
         for (int r = 0; r < BANK_ROWS; r++) out[(size_t)r * BANK_PITCH + k] = 0.0;
+#endif
         return;
     }
     const double tuning = tuning_of_slot(slot);
@@ -70,6 +74,9 @@ __global__ __launch_bounds__(256) void chroma_bank_kernel(double* __restrict__ b
     for (int r = 0; r < BANK_ROWS; r++) {
         double v = 0.0;
         if (r < 12) v = (w[(r + 3) % 12] / l2) * g;  // np.roll(-3) along the chroma axis
+#ifdef HP_CHECK_A
+        v = (double)(r * 8192 + k);  // probe build: every filter value names its own place (see chroma_handpipe.inc)
+#endif
         out[(size_t)r * BANK_PITCH + k] = v;
     }
 }
@@ -1023,6 +1030,10 @@ __device__ __forceinline__ double interval_feature(const double (&c)[12]) {
     return acc;
 }
 
+#ifdef CHROMA_HANDPIPE
+// probe build only (tests/tools/variant.sh): the withdrawn hand-pipelined contraction of round 2 in place of chroma_kernel
+#include "../../tests/tools/probes/handpipe/chroma_handpipe.inc"
+#else
 // One wavefront owns one 64-frame tile (= one chroma_part slot): four 16-frame MFMA sub-tiles share every
 // filter (A) fragment, so the L2-resident filter bank is read once per 64 frames instead of once per 16.
 __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs,
@@ -1156,6 +1167,8 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
         if (lane == 0) chroma_part[(size_t)(pfx_ct[s] + tile64) * 10 + t] = v;
     }
 }
+
+#endif  // CHROMA_HANDPIPE
 
 void launch_chroma(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.tiles_cw == 0) return;

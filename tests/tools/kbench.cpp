@@ -3,6 +3,8 @@
 //   build: g++ -std=c++17 -O1 -o tests/tools/kbench tests/tools/kbench.cpp -ldl
 //   usage: kbench <libblissgpu.so> [songs=256] [seconds=180] [steps=3] [ragged=0]
 //          kbench <libblissgpu.so> pairwise [n=100000] [reps=3]      the n x n euclidean matrix, self (A == B) and general
+//          KBENCH_DETERMINISM=R kbench <lib> [songs] [seconds] ...   R extra runs, every row compared bit for bit with the
+//                                                                    first run's (KBENCH_WS_LIMIT_MB cuts the batch into chunks)
 // Prints ms per kernel per step (HIP events on the stream each kernel runs on; KBENCH_SERIAL=1 for every kernel alone,
 // KBENCH_TAIL_MODE / KBENCH_PIPELINE_CHUNKS set the other scheduling options), the step's wall time, and an FNV-1a hash of the feature rows (two builds that agree bit for bit print the same hash).
 #include <dlfcn.h>
@@ -61,6 +63,8 @@ int main(int argc, char** argv) {
     SYM(blissgpu_profile_get) SYM(blissgpu_memcpy_d2h) SYM(blissgpu_ctx_set_option)
     blissgpu_ctx* c = nullptr;
     OK(p_blissgpu_ctx_create(0, &c));
+    SYM(blissgpu_ctx_set_workspace_limit)
+    if (const char* e = std::getenv("KBENCH_WS_LIMIT_MB")) OK(p_blissgpu_ctx_set_workspace_limit(c, (uint64_t)std::atoll(e) << 20));
     if (const char* e = std::getenv("KBENCH_SERIAL")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_SERIAL, std::atoi(e)));
     if (const char* e = std::getenv("KBENCH_TAIL_MODE")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_TAIL_MODE, std::atoi(e)));
     if (const char* e = std::getenv("KBENCH_PIPELINE_CHUNKS")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_PIPELINE_CHUNKS, std::atoi(e)));
@@ -105,6 +109,31 @@ int main(int argc, char** argv) {
     }
     std::vector<float> rows((size_t)n * 23);
     OK(p_blissgpu_memcpy_d2h(c, rows.data(), d_out, rows.size() * 4));
+    auto p_hp = (int (*)(unsigned long long*))dlsym(h, "blissgpu_debug_hp_mismatch");  // -DCHROMA_HANDPIPE -DHP_CHECK_A builds only
+    if (const char* e = std::getenv("KBENCH_DETERMINISM")) {
+        const int runs = std::atoi(e);
+        OK(p_blissgpu_profile_enable(c, 0));
+        std::vector<float> again(rows.size());
+        long bad_rows = 0, bad_runs = 0;
+        for (int r = 0; r < runs; r++) {
+            OK(p_blissgpu_analyze_batch_device(c, d_pcm, offs.data(), lens.data(), n, 2, d_out, nullptr));
+            OK(p_blissgpu_ctx_synchronize(c));
+            OK(p_blissgpu_memcpy_d2h(c, again.data(), d_out, again.size() * 4));
+            long b = 0;
+            for (uint32_t i = 0; i < n; i++)
+                if (std::memcmp(&again[(size_t)i * 23], &rows[(size_t)i * 23], 23 * 4) != 0) {
+                    if (b < 3) {
+                        std::printf("\n  run %d song %u differs:", r, i);
+                        for (int k = 0; k < 23; k++) if (again[(size_t)i * 23 + k] != rows[(size_t)i * 23 + k]) std::printf(" [%d] %.9g vs %.9g", k, again[(size_t)i * 23 + k], rows[(size_t)i * 23 + k]);
+                    }
+                    b++;
+                }
+            bad_rows += b; bad_runs += b != 0;
+        }
+        std::printf("\n  determinism: %d runs x %u songs, %ld differing rows in %ld runs", runs, n, bad_rows, bad_runs);
+        unsigned long long hp[2];
+        if (p_hp && p_hp(hp) == 0) std::printf("\n  handpipe filter check: %llu values read from the LDS ring differ from the bank (%llu wavefronts ran)", hp[0], hp[1]);
+    }
     uint64_t hash = 1469598103934665603ull;
     const unsigned char* b = (const unsigned char*)rows.data();
     for (size_t i = 0; i < rows.size() * 4; i++) { hash ^= b[i]; hash *= 1099511628211ull; }
