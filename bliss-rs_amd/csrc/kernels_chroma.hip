@@ -1,19 +1,23 @@
 // kernels_chroma.hip -- the chroma descriptor (src/chroma.rs) on the device.
 //
-//   chroma_bank_kernel : chroma_filter(22050, 8192, 12, tuning) (src/chroma.rs:197-267) for the 100
-//                        tunings pitch_tuning can return (+ tuning 0.0), built once per context.
-//   stft8192_kernel    : utils::stft(signal, 8192, 2205) (src/utils.rs:26-64): reflect pad, periodic
-//                        Hann (f32), FFT, |X| -- one workgroup per chroma frame, the 8192 real samples
-//                        packed as 4096 complex values, six Stockham radix-4 passes in LDS.  The f32
-//                        magnitudes (exactly the values the reference widens to f64) are stored for the
-//                        contraction; while the frame is still in LDS the kernel also runs pip_track's
-//                        peak test (src/chroma.rs:269-331) and counts peaks by coarse magnitude bin.
-//   tune_*_kernel      : estimate_tuning (src/chroma.rs:361-391): exact Midpoint median of the peak
-//                        magnitudes, then the 100-bin histogram of pitch residues of the peaks at or
-//                        above the median and its first argmax (pitch_tuning, :334-359).
-//   chroma_kernel      : chroma_stft (:393-412) as an f64 MFMA contraction filter(12x4097) x S^2,
-//                        followed per frame by the L1 normalisation, exp(15x), normalisation and the
-//                        10 interval templates x 12 rotations (:137-188), summed over the tile.
+//   chroma_bank_kernel : chroma_filter(22050, 8192, 12, tuning) (src/chroma.rs:197-267) for the 100 tunings
+//                        pitch_tuning can return (+ tuning 0.0), built once per context (f64, 40 MB).
+//   stft8192_kernel    : utils::stft(signal, 8192, 2205) (src/utils.rs:26-64): reflect pad, periodic Hann (f32), FFT,
+//                        |X|.  A 256-thread workgroup owns 16 frames of a song -- every FOURTH frame of a 64-frame
+//                        super-tile whose four workgroups share an XCD's L2, so the 73 % overlap of consecutive frames is
+//                        fetched from HBM once.  A frame's 8192 reals are 4096 complex values = 16 x 16 x 16: three
+//                        register radix-16 passes (fft_r16.hpp), two padded LDS transposes, a third LDS trip for the
+//                        mirrored real-input split.  The f32 magnitudes (exactly what the reference widens to f64) go to
+//                        HBM as 16-byte stores; while the row is still in LDS the kernel runs pip_track's peak test
+//                        (src/chroma.rs:269-331), classifies every peak (coarse magnitude bin, pitch-residue bin) into
+//                        one 32-bit record and counts the peaks by coarse magnitude bin.
+//   tune_*_kernel      : estimate_tuning (src/chroma.rs:361-391): the histogram locates the coarse bins of the two middle
+//                        order statistics, pass 2 walks the peak records (f64 only for the ~3 % that need it), the final
+//                        kernel radix-selects the exact Midpoint median among the candidates and takes the first
+//                        argmax of the 100-bin pitch histogram (pitch_tuning, :334-359).
+//   chroma_kernel      : chroma_stft (:393-412) as an f64 MFMA contraction filter(12 x 4097) x S^2, followed per frame by
+//                        the L1 normalisation, exp(15x), normalisation and the 10 interval templates x 12 rotations
+//                        (:137-188), summed per 64-frame tile.
 #include <float.h>
 #include <stdlib.h>
 

@@ -333,8 +333,7 @@ template <int D>
 static void launch_d(const float* A, uint64_t n, const float* B, uint64_t m, int metric, const float* M, int diag,
                      float* out, uint64_t ld, hipStream_t st) {
     const dim3 grid((uint32_t)((m + PW_COLS - 1) / PW_COLS), (uint32_t)((n + PW_ROWS - 1) / PW_ROWS));
-    static const bool no_sym = getenv("BLISSGPU_PW_NOSYM") != nullptr;  // developer aid: force the general kernel
-    if (A == B && n == m && !no_sym) {  // self-distance matrix: upper block triangle + mirrored stores
+    if (A == B && n == m) {  // self-distance matrix: upper block triangle + mirrored stores
         if (metric == METRIC_EUCLIDEAN)
             hipLaunchKernelGGL((pairwise_kernel<D, METRIC_EUCLIDEAN, false, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
         else if (metric == METRIC_COSINE)

@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage: KRE=regex bash tests/tools/pmc_one.sh   (two cheap SQ passes)
+# usage: KRE=regex [PMC_CMD="command"] bash tests/tools/pmc_one.sh   (two cheap SQ passes of the kernels matching KRE)
 R=$PWD; cd /tmp; export TMPDIR=/tmp; export KBENCH_SERIAL=1
 [ -x $R/tests/tools/kbench ] || g++ -std=c++17 -O1 -o $R/tests/tools/kbench $R/tests/tools/kbench.cpp -ldl
-B="$R/tests/tools/kbench $R/bliss-rs_amd/libblissgpu.so ${SONGS:-128} 180 1"
+B=${PMC_CMD:-"$R/tests/tools/kbench $R/bliss-rs_amd/libblissgpu.so ${SONGS:-128} 180 1"}
 rm -rf $R/gpurun_out/pmco
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" \
