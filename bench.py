@@ -608,6 +608,23 @@ def main():
                     res["note"] = "self-distance matrix of one library (A == B): upper block triangle computed, mirrored on store"
                 else:
                     res["general_A_ne_B"] = sec
+            # the reference's per-pair loop (src/playlist.rs:65-71, without its per-call allocations) on the host cores: a
+            # 1000 x m slab of the same matrix through the oracle, extrapolated to m x m -- and checked
+            try:
+                O = oracle_mod()
+                A_h = A.cpu().numpy()
+                slab = min(1000, m)
+                threads = min(os.cpu_count() or 1, 64)
+                t0 = time.perf_counter()
+                ref = O.pairwise(A_h[:slab], A_h, "euclidean", None, threads)
+                dtc = time.perf_counter() - t0
+                ctx.pairwise(A, B, "euclidean", out=D)
+                torch.cuda.synchronize()
+                res["cpu_baseline"] = {"pairs_per_sec": round(slab * m / dtc, 1), "threads": threads, "kind": "port",
+                                       "sample": f"oracle pairwise over a {slab} x {m} slab ({dtc:.2f} s), the m x m matrix would take {dtc * m / slab:.0f} s",
+                                       "slab_bit_identical_to_gpu": bool(np.array_equal(D[:slab].cpu().numpy(), ref))}
+            except Exception as e:  # noqa: BLE001
+                res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             return res
 
         if extras and not args.no_pairwise:

@@ -264,3 +264,24 @@ def test_c_shard_plan_edge_cases(bliss):
             assert prev == n
             L.blissgpu_row_block(n, world, world, C.byref(lo), C.byref(hi))  # no such rank: empty
             assert lo.value == hi.value == n
+
+
+def test_default_devices_env_parsing_without_a_gpu(bliss):
+    """BLISSGPU_DEFAULT_DEVICES restricts / orders / repeats the default contexts; parsing is device-free (the contexts
+    themselves are only created on first use, and fail with NO_DEVICE on a machine without a GPU)."""
+    code = r"""
+import ctypes, sys
+L = ctypes.CDLL(%r)
+n = L.blissgpu_default_device_count()
+print(n, [L.blissgpu_default_device(k) for k in range(n)], L.blissgpu_default_device(n), L.blissgpu_default_device(-1))
+""" % bliss.LIB_PATH
+    for env, want in (("0,0", "2 [0, 0] -1 -1"), ("2,0,5", "3 [2, 0, 5] -1 -1"), (" 1", "1 [1] -1 -1")):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                             env=dict(os.environ, BLISSGPU_DEFAULT_DEVICES=env))
+        assert out.returncode == 0 and out.stdout.strip() == want, (env, out.stdout, out.stderr)
+    import torch
+
+    if not torch.cuda.is_available():  # unset: one default device, whose context creation reports the missing GPU
+        env = {k: v for k, v in os.environ.items() if k != "BLISSGPU_DEFAULT_DEVICES"}
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert out.stdout.strip() == "1 [0] -1 -1", out.stdout + out.stderr

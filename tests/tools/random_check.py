@@ -70,6 +70,8 @@ def main():
                           "max_abs_err_non_tempo": float(err[:, 1:].max()), "worst_song_len": int(lens[worst]),
                           "songs_over_1e-5_non_tempo": int((err[:, 1:].max(axis=1) > 1e-5).sum()),
                           "tempo_mismatches_over_1e-4": int((err[:, 0] > 1e-4).sum()),
+                          "tempo_over_1e-5": int((err[:, 0] > 1e-5).sum()), "tempo_over_3e-5": int((err[:, 0] > 3e-5).sum()),
+                          "tempo_fraction_within_1e-5": round(float((err[:, 0] <= 1e-5).mean()), 6),
                           "max_abs_err_tempo": float(err[:, 0].max()), **detail}))
 
 
