@@ -363,3 +363,32 @@ def test_more_than_65535_songs_in_one_batch(bliss, oracle):
     err = np.abs(got[65535] - ref)
     assert (err[1:] <= _tol(N, 23, 1.0)[1:]).all() and err[0] <= 1e-4, err
     c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# distances at the edges of f32: denormal squares, overflow to inf, zeros / duplicates / negated rows
+# ---------------------------------------------------------------------------------------------
+def test_pairwise_is_bit_exact_at_the_edges_of_f32(bliss, oracle):
+    rng = np.random.default_rng(5)
+    d = 23
+    base = rng.uniform(-1, 1, (300, d)).astype(np.float32)
+    cases = {
+        "squares are denormal": base * np.float32(1e-22),
+        "tiny": base * np.float32(1e-19),
+        "squares near overflow": base * np.float32(1e18),
+        "squares overflow": base * np.float32(1e20),
+        "zeros, duplicates, negated rows": np.vstack([np.zeros((3, d), np.float32), base[:5], base[:5], -base[:5]]),
+        "mixed magnitudes": base * (np.float32(10.0) ** rng.integers(-12, 12, (300, 1)).astype(np.float32)),
+    }
+    M = np.diag(rng.uniform(0.1, 2, d).astype(np.float32)).astype(np.float32)
+    R = rng.uniform(-1, 1, (d, d)).astype(np.float32)
+    P = (R @ R.T).astype(np.float32)
+    for name, X in cases.items():
+        for metric, m in (("euclidean", None), ("cosine", None), ("mahalanobis", M), ("mahalanobis", P)):
+            with np.errstate(all="ignore"):
+                got = bliss.playlist.pairwise_distances(X, X[:97], metric, m)
+                ref = oracle.pairwise(X, X[:97], metric, m)
+            assert np.array_equal(got, ref, equal_nan=True), (name, metric)
+        with np.errstate(all="ignore"):   # the self-distance kernel (A is B): mirrored blocks
+            got = bliss.playlist.pairwise_distances(X, X, "euclidean")
+            assert np.array_equal(got, oracle.pairwise(X, X, "euclidean"), equal_nan=True), name
