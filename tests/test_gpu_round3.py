@@ -392,3 +392,48 @@ def test_pairwise_is_bit_exact_at_the_edges_of_f32(bliss, oracle):
         with np.errstate(all="ignore"):   # the self-distance kernel (A is B): mirrored blocks
             got = bliss.playlist.pairwise_distances(X, X, "euclidean")
             assert np.array_equal(got, oracle.pairwise(X, X, "euclidean"), equal_nan=True), name
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's REAL audio (its golden song, its piano recording) cut, mixed and stretched into a battery: tonal
+# material with real tunings, real beats and real silences, not white noise
+# ---------------------------------------------------------------------------------------------
+def test_real_audio_battery_vs_oracle(bliss, ctx, oracle, golden_pcm, piano_pcm, literals):
+    g = golden_pcm.astype(np.float32)
+    p = piano_pcm.astype(np.float32)
+    n = min(len(g), len(p))
+    songs = {
+        "golden": g,
+        "piano": p,
+        "golden x4": np.tile(g, 4),
+        "golden reversed": g[::-1].copy(),
+        "piano then golden": np.concatenate([p, g]),
+        "mix 0.5 golden + 0.5 piano": (np.float32(0.5) * g[:n] + np.float32(0.5) * p[:n]).astype(np.float32),
+        "2 s of silence, then golden": np.concatenate([np.zeros(2 * 22050, np.float32), g]),
+        "golden, then 3 s of silence": np.concatenate([g, np.zeros(3 * 22050, np.float32)]),
+        "golden second half": g[len(g) // 2:].copy(),
+        "piano at 1e-3": (p * np.float32(1e-3)).astype(np.float32),
+        "golden, first 8192 samples": g[:8192].copy(),
+        "golden, 60 000 samples from 50 000": g[50000:110000].copy(),
+    }
+    names = list(songs)
+    for version in (2, 1):
+        got, status = _run(ctx, [songs[k] for k in names], version)
+        assert (status == 0).all()
+        tuning, n_bpms = ctx.last_tuning(len(names))
+        over = []
+        for i, k in enumerate(names):
+            ref = oracle.song_analyze(songs[k], version)
+            _, otuning = oracle.chroma_desc(songs[k])
+            err = np.abs(got[i] - ref)
+            assert abs(tuning[i] - otuning) < 1e-12, (k, tuning[i], otuning)          # the tuning estimate is exact
+            assert (err[1:] <= _tol(len(songs[k]), len(ref), 1.0)[1:]).all(), (k, version, err)
+            assert err[0] <= 1e-4, (k, version, float(err[0]))
+            if err[0] > 1e-5:
+                over.append((k, float(err[0])))
+        print("tempo over 1e-5:", over)
+        assert len(over) <= 1, over
+        # the golden song keeps the reference's own literals when it sits inside a batch of other material
+        key = "analysis_v2_s16_mono_22_5kHz" if version == 2 else "analysis_v1_s16_mono_22_5kHz"
+        exp = np.array(literals[key]["values"], np.float32)
+        assert np.abs(got[0] - exp).max() < literals[key]["tol"], (version, got[0] - exp)
