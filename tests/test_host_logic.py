@@ -152,10 +152,11 @@ from bliss_rs_amd.shard import shard_songs, all_gather_features, row_block
 import oracle as O
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-lengths = [9000, 30000, 8192, 12000, 20000]
+lengths = [9000, 30000, 8192, 12000, 20000][:int(os.environ["N_SONGS"])]
 mine = shard_songs(lengths, world)[rank]
 # the per-rank analysis is stood in for by the CPU oracle (the sharding + collective is what is under test)
-rows = np.stack([O.song_analyze(O.white_noise(int(i), lengths[int(i)])) for i in mine])
+rows = (np.stack([O.song_analyze(O.white_noise(int(i), lengths[int(i)])) for i in mine]) if len(mine)
+        else np.zeros((0, 23), np.float32))   # a rank may own no song at all
 full = all_gather_features(torch.from_numpy(rows), mine, len(lengths))
 ref = np.stack([O.song_analyze(O.white_noise(i, n)) for i, n in enumerate(lengths)])
 assert np.array_equal(full.numpy(), ref), "gathered matrix differs"
@@ -175,15 +176,17 @@ print("rank", rank, "ok")
 """
 
 
-def test_two_rank_gloo_shard_and_all_gather(tmp_path):
+@pytest.mark.parametrize("world,n_songs", [(2, 5), (4, 3)])   # (4, 3): ragged shards, one rank owns nothing
+def test_gloo_shard_and_all_gather(tmp_path, world, n_songs):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   N_SONGS=str(n_songs))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
