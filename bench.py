@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--traffic", action="store_true",
                     help="measure roofline.traffic now (two rocprofv3 --pmc passes of a 256-song batch, ~1 min) instead of "
                          "reading profiles/hbm_traffic.json")
+    ap.add_argument("--share-device", action="store_true",
+                    help="developer check on a 1-GPU box: every rank of an N > 1 launch uses device 0 and the collectives "
+                         "go over gloo (RCCL refuses two ranks on one device); exercises the N > 1 control flow, the line "
+                         "is marked and is not a measurement")
     ap.add_argument("--node", type=int, default=0,
                     help="drive N GPUs from THIS process through the C-ABI node API (blissgpu_node_*: what a Rust host "
                          "would call) instead of one torch.distributed rank per GPU; configs batch / library")
@@ -289,10 +293,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the library has no CPU path")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.share_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     ctx = bliss.Context(local_rank)
     if args.serial:
@@ -371,7 +380,9 @@ def main():
     def step():
         ctx.analyze(pcm, offs, lens, version, out=out, status=status)
         full = out
-        if world > 1:
+        if world > 1 and args.share_device:   # gloo gathers host tensors only
+            full = all_gather_features(out.cpu(), global_idx_dev.cpu(), n_total, n_local_max=n_local_max).cuda()
+        elif world > 1:
             full = all_gather_features(out, global_idx_dev, n_total, n_local_max=n_local_max)
         if args.config == "library":
             lo, hi = row_block(n_total, rank, world)
@@ -408,9 +419,10 @@ def main():
     prof = ctx.profile()
     ctx.profile_enable(False)
     chunks = ctx.last_chunks()
-    tot = torch.tensor([float(n), float(total_samples)], dtype=torch.float64, device="cuda")
+    red_dev = "cpu" if args.share_device else "cuda"
+    tot = torch.tensor([float(n), float(total_samples)], dtype=torch.float64, device=red_dev)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -485,6 +497,9 @@ def main():
             "roofline": roofline, "roofline_fp32": fp32,
         }
         result.update(notes)
+        if args.share_device:
+            result["share_device"] = (f"{world} ranks on ONE device, collectives over gloo through the host: a check of the "
+                                      f"N > 1 control flow on a 1-GPU box, not a measurement")
 
         # The headline numbers above are complete at this point; the sections below are extras.  Each one is guarded so
         # that a failure there (a full host, no room for the 40 GB distance matrix, ...) is reported inside the JSON

@@ -437,3 +437,32 @@ def test_real_audio_battery_vs_oracle(bliss, ctx, oracle, golden_pcm, piano_pcm,
         key = "analysis_v2_s16_mono_22_5kHz" if version == 2 else "analysis_v1_s16_mono_22_5kHz"
         exp = np.array(literals[key]["values"], np.float32)
         assert np.abs(got[0] - exp).max() < literals[key]["tol"], (version, got[0] - exp)
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py launched the way the driver launches N > 1 (torch.distributed.run, one rank per GPU) -- on this 1-GPU box the
+# ranks share device 0 and the collectives go over gloo (--share-device); everything else is the N > 1 code as it runs
+# on a node: per-rank shares, the gathered matrix, the row-block distance kernel, max-over-ranks timing, one JSON line
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("config", ["batch", "library", "mixed"])
+def test_bench_two_ranks_sharing_the_device(config):
+    import json
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--config", config, "--songs", "24", "--samples", "400000", "--share-device", "--no-cpu-baseline", "--no-pairwise",
+           "--no-host-feed", "--no-playlist", "--no-small-calls"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                      # rank 0 prints ONE line
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1
+    assert r["config"]["songs_total"] == 48                          # both ranks' shares were summed
+    assert r["scaling"] == ("strong" if config == "library" else "weak")
+    assert r["value"] > 0 and abs(r["value"] - 48 * 2 / (r["ms_per_step"] * 2e-3)) < 0.01 * r["value"]
+    assert r["roofline"]["frac"] > 0 and "share_device" in r
