@@ -466,3 +466,33 @@ def test_bench_two_ranks_sharing_the_device(config):
     assert r["scaling"] == ("strong" if config == "library" else "weak")
     assert r["value"] > 0 and abs(r["value"] - 48 * 2 / (r["ms_per_step"] * 2e-3)) < 0.01 * r["value"]
     assert r["roofline"]["frac"] > 0 and "share_device" in r
+
+
+# ---------------------------------------------------------------------------------------------
+# a two-hour song (a DJ set, an audio book): 158 760 000 samples, 1.24 million timbral frames, 72 000 chroma frames in ONE
+# song, twelve times the longest song of the mixed corpus -- beside a 30-second song in the same batch
+# ---------------------------------------------------------------------------------------------
+def test_two_hour_song_vs_oracle(bliss, oracle):
+    import torch
+
+    c = bliss.Context(0)
+    lens = np.array([2 * 3600 * 22050, 30 * 22050 + 7], np.uint64)
+    offs = np.array([0, (int(lens[0]) + 63) // 64 * 64], np.uint64)
+    pcm = torch.empty(int(offs[1]) + int(lens[1]) + 64, dtype=torch.float32, device="cuda")
+    c.synth_white_noise(pcm, offs, lens, first_song_index=7777)
+    out, status = c.analyze(pcm, offs, lens, 2)
+    c.synchronize()
+    got = out.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all() and np.isfinite(got).all()
+    # the device generator and the oracle's are the same function of (song index, sample index)
+    x = oracle.white_noise(7777, int(lens[0]))
+    assert np.array_equal(pcm[:1 << 20].cpu().numpy(), x[:1 << 20])
+    assert np.array_equal(pcm[int(lens[0]) - 4096:int(lens[0])].cpu().numpy(), x[-4096:])
+    for i, sig in enumerate((x, oracle.white_noise(7778, int(lens[1])))):
+        err = np.abs(got[i] - oracle.song_analyze(sig))
+        assert (err[1:] <= _tol(len(sig), 23, 1.0)[1:]).all() and err[0] <= 1e-4, (i, err)
+    # and alone = in company
+    alone, _ = c.analyze(pcm, offs[:1], lens[:1], 2)
+    c.synchronize()
+    assert np.array_equal(alone.cpu().numpy()[0], got[0])
+    c.close()
