@@ -573,7 +573,8 @@ def main():
                               res.ctypes.data, st.ctypes.data_as(C.POINTER(C.c_int32))))
                 return hf / (time.perf_counter() - t0)
 
-            run(L.blissgpu_analyze_batch, h_f32.data_ptr())  # warm-up (allocations)
+            run(L.blissgpu_analyze_batch, h_f32.data_ptr())       # warm-up: the context allocates its staging buffers
+            run(L.blissgpu_analyze_batch_s16, h_s16.data_ptr())   # ... and the raw-sample buffers of the s16 form
             feed = {"songs": hf,
                     "f32_pinned_songs_per_sec": round(run(L.blissgpu_analyze_batch, h_f32.data_ptr()), 1),
                     "f32_pageable_songs_per_sec": round(run(L.blissgpu_analyze_batch, pageable.ctypes.data), 1),

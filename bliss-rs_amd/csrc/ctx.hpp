@@ -87,13 +87,19 @@ struct ChunkSlot {
 };
 
 // Persistent staging of the host-pointer entry points (the PCM feed): two device PCM buffers (+ raw s16 / multi-channel
-// staging), two result buffers, a copy stream and the events that order them.  Grow-only; guarded by the context mutex.
+// staging), two result buffers, two copy streams (songs alternate between them: one stream moves 54.5 GB/s from pinned
+// memory, two 57.3 -- tests/tools/probes/h2d_probe.hip) and the events that order them.  Grow-only; guarded by the
+// context mutex.
+#ifndef FEED_COPY_STREAMS
+#define FEED_COPY_STREAMS 2
+#endif
+constexpr int N_COPY_STREAMS = FEED_COPY_STREAMS;
 struct HostFeed {
     DevBuf<float> pcm[2];
     DevBuf<uint8_t> raw[2];
     DevBuf<float> out[2];
-    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2][N_COPY_STREAMS] = {}, ev_done[2] = {nullptr, nullptr};
+    hipStream_t copy_stream[N_COPY_STREAMS] = {};
 };
 
 }  // namespace bg

@@ -255,12 +255,14 @@ void scheduler_release(blissgpu_ctx* c) {
         s = ChunkSlot{};
     }
     HostFeed& f = c->feed;
-    if (f.copy_stream) { (void)hipStreamSynchronize(f.copy_stream); (void)hipStreamDestroy(f.copy_stream); f.copy_stream = nullptr; }
+    for (hipStream_t& cs : f.copy_stream)
+        if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); cs = nullptr; }
     for (int b = 0; b < 2; b++) {
         f.pcm[b].release(); f.raw[b].release(); f.out[b].release();
-        if (f.ev_copied[b]) (void)hipEventDestroy(f.ev_copied[b]);
+        for (hipEvent_t& ev : f.ev_copied[b])
+            if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
         if (f.ev_done[b]) (void)hipEventDestroy(f.ev_done[b]);
-        f.ev_copied[b] = f.ev_done[b] = nullptr;
+        f.ev_done[b] = nullptr;
     }
 }
 
@@ -272,6 +274,9 @@ void scheduler_release(blissgpu_ctx* c) {
 // downmixed there ((L + R) * SQRT_2 / 2 for stereo, the channel mean otherwise: src/song/decoder/symphonia.rs:266-300).
 // All staging lives in the context and is reused by later calls.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef FEED_GROUP_MIB
+#define FEED_GROUP_MIB 512
+#endif
 int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t* lengths, uint32_t n_songs,
                        int bytes_per_sample, uint32_t channels, uint32_t features_version, float* out, int32_t* status,
                        const char* who, float* d_rows) {
@@ -282,19 +287,23 @@ int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t*
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     HostFeed& f = c->feed;
-    if (!f.copy_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&f.copy_stream, hipStreamNonBlocking));
+    if (!f.copy_stream[N_COPY_STREAMS - 1]) {
+        for (hipStream_t& cs : f.copy_stream)
+            if (!cs) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         for (int b = 0; b < 2; b++) {
-            HIP_TRY(hipEventCreateWithFlags(&f.ev_copied[b], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&f.ev_done[b], hipEventDisableTiming));
+            for (hipEvent_t& ev : f.ev_copied[b])
+                if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            if (!f.ev_done[b]) HIP_TRY(hipEventCreateWithFlags(&f.ev_done[b], hipEventDisableTiming));
         }
     }
     const bool direct = bytes_per_sample == 4 && channels == 1;  // f32 mono: copied verbatim into the PCM buffer
     const size_t frame_bytes = (size_t)bytes_per_sample * channels;
-    // groups of <= 2 GiB of staging (mono f32: ~128 three-minute songs): large enough to fill the GPU, small enough to
-    // pipeline.  The cap is in BYTES of the wider of the two buffers of a group (raw interleaved frames / mono f32), so an
-    // 8-channel f32 batch stages 2 x 2 GiB like a mono one instead of 2 x 16 GiB.
-    const uint64_t group_cap = (2048ull << 20) / std::max<size_t>(4, frame_bytes);  // frames
+    // groups of <= 512 MiB of staging (mono f32: ~32 three-minute songs).  The transfer is the bottleneck (a group's
+    // analysis takes a tenth of its transfer time), so what a call pays beyond its bytes is the analysis of the LAST group:
+    // small groups keep that tail short, and 32 songs still fill the GPU several times over.  The cap is in BYTES of the
+    // wider of the two buffers of a group (raw interleaved frames / mono f32), so an 8-channel f32 batch stages
+    // 2 x 512 MiB like a mono one instead of 2 x 4 GiB.
+    const uint64_t group_cap = ((uint64_t)FEED_GROUP_MIB << 20) / std::max<size_t>(4, frame_bytes);  // frames
     struct Group { uint32_t i0, n; std::vector<uint64_t> doff, dlen; uint64_t total; };
     std::vector<Group> groups;
     for (uint32_t i0 = 0; i0 < n_songs;) {
@@ -326,13 +335,16 @@ int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t*
         const int b = (int)(gi % nbuf);
         // buffer b is free again once the analysis that last read it (this call's group gi - 2, or an earlier call:
         // every call ends synchronised) has finished
-        hipError_t ee = gi >= (size_t)nbuf ? hipStreamWaitEvent(f.copy_stream, f.ev_done[b], 0) : hipSuccess;
+        hipError_t ee = hipSuccess;
+        for (int q = 0; q < N_COPY_STREAMS && ee == hipSuccess && gi >= (size_t)nbuf; q++)
+            ee = hipStreamWaitEvent(f.copy_stream[q], f.ev_done[b], 0);
         for (uint32_t k = 0; k < g.n && ee == hipSuccess; k++)
             if (g.dlen[k]) {
                 void* dst = direct ? (void*)(f.pcm[b].p + g.doff[k]) : (void*)(f.raw[b].p + g.doff[k] * frame_bytes);
-                ee = hipMemcpyAsync(dst, ptrs[g.i0 + k], g.dlen[k] * frame_bytes, hipMemcpyHostToDevice, f.copy_stream);
+                ee = hipMemcpyAsync(dst, ptrs[g.i0 + k], g.dlen[k] * frame_bytes, hipMemcpyHostToDevice,
+                                    f.copy_stream[k % N_COPY_STREAMS]);
             }
-        if (ee == hipSuccess) ee = hipEventRecord(f.ev_copied[b], f.copy_stream);
+        for (int q = 0; q < N_COPY_STREAMS && ee == hipSuccess; q++) ee = hipEventRecord(f.ev_copied[b][q], f.copy_stream[q]);
         return ee;
     };
 
@@ -340,7 +352,11 @@ int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t*
     for (size_t gi = 0; gi < groups.size() && e == hipSuccess && !rc; gi++) {
         const Group& g = groups[gi];
         const int b = (int)(gi % nbuf);
-        e = hipStreamWaitEvent(c->stream, f.ev_copied[b], 0);
+        // The next group's transfer is queued BEFORE this group's analysis is enqueued (its buffer was released by the
+        // event group gi - 1 recorded): enqueuing an analysis can block the host on an earlier chunk's events, and the
+        // link must not run dry meanwhile.  (Pageable sources block the host here, not the GPU.)
+        if (gi + 1 < groups.size()) e = upload(gi + 1);
+        for (int q = 0; q < N_COPY_STREAMS && e == hipSuccess; q++) e = hipStreamWaitEvent(c->stream, f.ev_copied[b][q], 0);
         if (e != hipSuccess) break;
         if (!direct) {
             launch_pcm_convert(f.raw[b].p, bytes_per_sample, channels, f.pcm[b].p, g.total, c->stream);
@@ -353,14 +369,17 @@ int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t*
         if (e == hipSuccess && d_rows)
             e = hipMemcpyAsync(d_rows + (size_t)g.i0 * d, f.out[b].p, (size_t)g.n * d * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
         if (e == hipSuccess) e = hipEventRecord(f.ev_done[b], c->stream);
-        // the next group's transfer overlaps this group's kernels (pageable sources block the host here, not the GPU)
-        if (e == hipSuccess && gi + 1 < groups.size()) e = upload(gi + 1);
         if (status)
             for (uint32_t k = 0; k < g.n; k++)
                 status[g.i0 + k] = g.dlen[k] >= (uint64_t)MIN_SAMPLES ? BLISSGPU_SONG_OK : BLISSGPU_SONG_TOO_SHORT;
     }
     // every exit leaves the streams drained: the staging buffers belong to the next call
-    const hipError_t e1 = hipStreamSynchronize(f.copy_stream), e2 = hipStreamSynchronize(c->stream);
+    hipError_t e1 = hipSuccess;
+    for (hipStream_t cs : f.copy_stream) {
+        const hipError_t eq = hipStreamSynchronize(cs);
+        if (e1 == hipSuccess) e1 = eq;
+    }
+    const hipError_t e2 = hipStreamSynchronize(c->stream);
     if (rc) return rc;
     if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
     if (e != hipSuccess) return fail(BLISSGPU_ERR_HIP, who, hipGetErrorString(e));
