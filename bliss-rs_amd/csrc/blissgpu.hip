@@ -20,7 +20,7 @@ thread_local std::string g_last_error;
 
 const char* const kKernelNames[K_COUNT] = {
     "fft512_kernel",     "onset_kernel",      "beat_kernel",   "stft8192_kernel", "tune_select_kernel",
-    "tune_pass2_kernel", "tune_final_kernel", "chroma_kernel",     "summary_kernel", "assemble_kernel", "pairwise_kernel", "set_distance_kernel", "song_to_song_kernel", "synth_kernel"};
+    "tune_pass2_kernel", "tune_final_kernel", "chroma_kernel",     "summary_kernel", "assemble_kernel", "pairwise_kernel", "set_distance_kernel", "song_to_song_kernel", "synth_kernel", "rolloff_fix_kernel"};
 }  // namespace
 
 namespace bg {
@@ -287,6 +287,7 @@ int blissgpu_ctx_set_option(blissgpu_ctx* c, int option, int64_t value) {
         case BLISSGPU_OPT_SERIAL: c->serial = value != 0; break;
         case BLISSGPU_OPT_TAIL_MODE: c->tail_mode = (int)value; break;
         case BLISSGPU_OPT_PIPELINE_CHUNKS: c->pipeline_chunks = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); break;
+        case BLISSGPU_OPT_ROLLOFF_EXACT_ALL: c->rolloff_exact_all = value != 0; break;
         case BLISSGPU_OPT_CAND_BUDGET: c->cand_budget = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 714)); break;
         default: return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_set_option", "unknown option");
     }

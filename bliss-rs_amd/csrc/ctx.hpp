@@ -118,6 +118,7 @@ struct blissgpu_ctx {
     uint32_t pipeline_chunks = 1;      // cut big batches into at least this many chunks (BLISSGPU_OPT_PIPELINE_CHUNKS; measured: the
                                        // per-song tails have a fixed latency per launch, so more chunks than memory needs lose)
     hipEvent_t ev_interop = nullptr;
+    bool rolloff_exact_all = false;    // BLISSGPU_OPT_ROLLOFF_EXACT_ALL (tests)
     bool serial = false;               // BLISSGPU_OPT_SERIAL: single stream (clean per-kernel timings)
     uint64_t ws_limit = 0;             // bytes per chunk slot (set from the free device memory at creation)
     uint32_t cand_budget = bg::CAND_BUDGET_PER_FRAME;  // tuning-candidate pool: slots per chroma frame of a chunk

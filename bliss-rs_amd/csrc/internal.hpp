@@ -52,6 +52,18 @@ struct SongDesc {
     uint32_t ok;        // 1 = analyse, 0 = too short (status already set by the host)
 };
 
+// Frames whose rolloff bin the FFT-512 kernel could not prove (see its epilogue) are handed to rolloff_fix_kernel: 256
+// magnitudes + the frame's index in the series arrays each.  The record lives in device memory (filled by the host per
+// chunk); the entries borrow the memory of the spectrogram and the peak records, dead until the FFT-8192 kernel starts --
+// room for every frame of the chunk.
+struct RollFix {
+    float* mags;        // [cap][256]
+    uint32_t* frame;    // [cap]
+    uint32_t* cursor;   // [0] entries requested (may exceed cap); in a cache line of its own: every unproven frame of the
+                        // launch does an atomic on it, and the record itself is read-only
+    uint32_t cap;
+};
+
 // Per-song scalars produced by the tuning stage.
 struct TuningState {
     uint32_t n_peaks;      // total pip_track peaks
@@ -92,6 +104,7 @@ enum KernelId : int {
     K_FINALIZE,
     K_PAIRWISE, K_SET_DISTANCE, K_SONG_TO_SONG,
     K_SYNTH,
+    K_ROLLFIX,
     K_COUNT
 };
 
@@ -133,6 +146,9 @@ struct Workspace {
     uint32_t runs_pitch;
     float* bt_pre;          // [total_b / 128 + n_songs][BT_PRE_STRIDE] per-run records; song s starts at run b_off / 128 + s
     float* summary;         // [n_songs][16] features 1..9 (zcr, timbral, loudness summaries)
+    RollFix* roll_fix;      // the exact rolloff pass's record (see RollFix)
+    uint32_t* roll_fix_cursor;
+    size_t roll_fix_bytes;  // the borrowed stretch: spectrogram + peak records
 };
 
 struct Batch {
@@ -150,7 +166,8 @@ struct Batch {
     uint32_t max_nt;          // longest song's timbral-frame count
 };
 
-void launch_fft512(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
+void launch_fft512(const Batch&, const Workspace&, const DeviceTables&, hipStream_t, bool rolloff_exact_all = false);
+void launch_rolloff_fix(const Batch&, const Workspace&, uint64_t total_t, hipStream_t);
 void launch_onset(const Batch&, const Workspace&, hipStream_t);
 void launch_beat(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
 void launch_stft8192(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);

@@ -23,6 +23,7 @@
 // frames so the previous tempo frame's magnitudes stay in registers (one halo FFT per group).  The lane's
 // constants (window, twiddles) are register resident: two waves per SIMD without table reads beat three
 // waves with LDS tables.
+#include <float.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -35,6 +36,9 @@ namespace bg {
 
 constexpr int GROUPS_PER_WG = 16;
 constexpr int FRAMES_PER_GROUP = F512_TILE / GROUPS_PER_WG;
+// rolloff: distance (relative to the frame's energy) below which the parallel and the sequential summation orders might
+// disagree about a bin; 704 u, u = 2^-24 (see the frame epilogue)
+constexpr float ROLL_GUARD = 704.0f / 16777216.0f;
 constexpr int GRP_PITCH = 272;  // float2 per group tile: 16 rows of 17, and == 128 B (mod 256 B) between groups
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -194,6 +198,7 @@ __device__ __forceinline__ void stats128(const f2 r0, const f2 r1, const f2 r2, 
     add_lane_bit(zc, x3 ^ shifted(y3, (y2 >> 15) & LOW));
 }
 
+template <bool ROLLOFF_EXACT_ALL>  // true: tests only -- every frame takes the reference-order pass
 __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict__ pcm,
                                                         const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                         const uint32_t* __restrict__ pfx_f,
@@ -201,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
                                                         const float2* __restrict__ tw512,
                                                         float* __restrict__ centroid, float* __restrict__ rolloff,
                                                         float* __restrict__ flatness, float* __restrict__ flux,
-                                                        float* __restrict__ e256, uint32_t* __restrict__ zc256) {
+                                                        float* __restrict__ e256, uint32_t* __restrict__ zc256,
+                                                        const RollFix* __restrict__ fix) {
     __shared__ f2 lds[GROUPS_PER_WG * GRP_PITCH];
     RegTables tabs;
     {
@@ -304,19 +310,34 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
             const float wsum = (float)(16 * l) * sum + (e2.x + e2.y);  // sum (16 l + e) m_e
             const float total = row16_sum(sum);
             const float wtotal = row16_sum(wsum);
-            // spectral_rolloff (src/aubio.rs:36-58): bins consumed until the running energy reaches 95 %
+            // spectral_rolloff (src/aubio.rs:36-58): bins consumed until the running energy reaches 95 %.  The reference
+            // adds the 256 squares one by one in f32; here a lane scan supplies the energy below the lane's first bin and
+            // the lane walks its 16 bins.  A bin COUNT is discontinuous in those sums, so the two orders must not be
+            // allowed to disagree: the walk is carried as d = (running energy) - threshold, and a frame in which some |d|
+            // comes within ROLL_GUARD x total of zero -- closer than the worst-case rounding of both orders together:
+            // 256 u + 257 u for the sequential sums of total and running energy, < 100 u for the scan, the tree, the fused
+            // squares and the walk (u = 2^-24) -- hands its 256 magnitudes to rolloff_fix_kernel, which repeats the
+            // reference's loop literally (about 2 % of white-noise frames; every other frame's count is provably the
+            // sequential one).
             const float incl = row16_scan_incl(sqsum);
             const float cum_total = row16_sum(sqsum);
             const float thr = cum_total * 0.95f;
-            float run = incl - sqsum;
-            int below = 0;
+            float d = (incl - sqsum) - thr;
+            float near = FLT_MAX;
+            uint32_t signs = 0;  // sign bit of d after each bin, shifted in: d < 0 <=> that bin is still below the threshold
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const float me = e == 15 ? m15 : cur.m[e];
-                run += me * me;
-                below += (run < thr) ? 1 : 0;
+            for (int i = 0; i < 8; i++) {
+                const float m0 = cur.m[2 * i], m1 = i == 7 ? m15 : cur.m[2 * i + 1];
+                const float d0 = fmaf(m0, m0, d);
+                d = fmaf(m1, m1, d0);
+                signs = __builtin_amdgcn_alignbit(signs, __float_as_uint(d0), 31);  // (signs << 1) | (d0 < 0)
+                signs = __builtin_amdgcn_alignbit(signs, __float_as_uint(d), 31);
+                asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(near) : "v"(d0), "v"(d));
             }
-            const int c = row16_sum(below);
+            const int c = row16_sum((int)__popc(signs));
+            // not (near > guard): also catches NaN; totals in the denormal range have no relative bound; a frame of digital
+            // silence is 0 in either order
+            const bool risky = ROLLOFF_EXACT_ALL || (cum_total != 0.0f && (!(near > cum_total * ROLL_GUARD) || cum_total < 1e-30f));
             // geometric_mean (src/utils.rs:101-117): groups of 8 in f64, exponents and mantissas apart
             int expo = 0, zero = 0;
             double mant = 1.0;
@@ -345,6 +366,27 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
             st_wtotal = mine ? wtotal : st_wtotal;
             st_ints = mine ? packed : st_ints;
             st_mant = mine ? (float)mant : st_mant;
+            // (at the very end of the frame: the branch splits the block the scheduler works on)
+            const uint64_t risky_lanes = __ballot(risky);
+            if (risky_lanes != 0) {  // wave-uniform; rare
+                const uint32_t grp_mask = (uint32_t)(risky_lanes >> (threadIdx.x & 48)) & 0xFFFFu;
+                if (grp_mask != 0) {  // this frame goes to the exact pass
+                    // (the pass's buffers are named by a record in memory, read only here: four more kernel arguments would
+                    // live in SGPRs through the whole frame loop, which has none to spare)
+                    uint32_t slot = 0;
+                    if (l == 0) slot = atomicAdd(fix->cursor, 1u);
+                    slot = (uint32_t)__shfl((int)slot, (int)(threadIdx.x & 48), 64);
+                    if (slot < fix->cap) {
+                        uint32_t* fix_frame = fix->frame;
+                        float4* dst = reinterpret_cast<float4*>(fix->mags + (size_t)slot * 256 + 16 * l);
+                        dst[0] = make_float4(cur.m[0], cur.m[1], cur.m[2], cur.m[3]);
+                        dst[1] = make_float4(cur.m[4], cur.m[5], cur.m[6], cur.m[7]);
+                        dst[2] = make_float4(cur.m[8], cur.m[9], cur.m[10], cur.m[11]);
+                        dst[3] = make_float4(cur.m[12], cur.m[13], cur.m[14], m15);
+                        if (l == 0) fix_frame[slot] = (uint32_t)(sd.t_off + (uint64_t)k);
+                    }
+                }
+            }
         }
     };
     // finish the frames [k16, k16 + 16) whose sums the lanes hold (lane l: frame k16 + l)
@@ -400,10 +442,10 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
     }
 }
 
-void launch_fft512(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
+void launch_fft512(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st, bool rolloff_exact_all) {
     if (b.tiles_f == 0) return;
-    hipLaunchKernelGGL(fft512_kernel, dim3(b.tiles_f), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_f, t.hannz512,
-                       t.tw512, w.centroid, w.rolloff, w.flatness, w.flux, w.e256, w.zc256);
+    hipLaunchKernelGGL(rolloff_exact_all ? fft512_kernel<true> : fft512_kernel<false>, dim3(b.tiles_f), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_f, t.hannz512,
+                       t.tw512, w.centroid, w.rolloff, w.flatness, w.flux, w.e256, w.zc256, w.roll_fix);
 }
 
 }  // namespace bg

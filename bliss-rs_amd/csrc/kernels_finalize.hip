@@ -192,6 +192,77 @@ __global__ __launch_bounds__(64) void assemble_kernel(const SongDesc* __restrict
     dbg_nbpms[sd.row] = tempo[s].n_bpms;
 }
 
+// ------------------------------------------------------------------------------------------------
+// spectral_rolloff (src/aubio.rs:36-58) as the reference writes it -- the 256 squares added one by one in f32, twice --
+// for the frames whose bin count the FFT-512 kernel could not prove from its own summation order (a running energy within
+// worst-case rounding of the 95 % threshold).  Thread per frame; this translation unit never fuses a * b + c.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rolloff_fix_kernel(const RollFix* __restrict__ fix, float* __restrict__ rolloff) {
+    // One wavefront per 64 frames, a lane per frame.  A frame's 256 magnitudes are 1 KB apart from its neighbour's: they
+    // are fetched with coalesced 16-byte loads (four frames x 256 B per instruction) into a padded LDS tile, 64 bins of all
+    // 64 frames at a time, and every lane then walks its own row.  (Keeping all 256 bins of the 64 frames in LDS -- one
+    // read instead of two -- leaves two wavefronts per CU and takes twice as long: 0.47 vs 0.23 ms per 512 songs.)
+    __shared__ float tile[64 * 65];
+    const uint32_t n = min(fix->cursor[0], fix->cap);
+    const float* __restrict__ mags = fix->mags;
+    const uint32_t* __restrict__ frame = fix->frame;
+    const float freq_per_bin = (float)SAMPLE_RATE / (float)W512;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {
+        auto load_piece = [&](int p) {
+            __syncthreads();
+#pragma unroll 4
+            for (uint32_t q = 0; q < 16; q++) {
+                const uint32_t e = 4 * q + (lane >> 4), f4 = lane & 15;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (base + e < n) v = *reinterpret_cast<const float4*>(mags + (size_t)(base + e) * 256 + 64 * p + 4 * f4);
+                float* t = tile + e * 65 + 4 * f4;
+                t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+            }
+            __syncthreads();
+        };
+        const float* __restrict__ row = tile + lane * 65;
+        float cumsum = 0.0f, upto[4];  // upto[p]: the running sum after piece p -- what `rollsum` will be there as well
+        for (int p = 0; p < 4; p++) {
+            load_piece(p);
+#pragma unroll 16
+            for (int j = 0; j < 64; j++) cumsum += row[j] * row[j];
+            upto[p] = cumsum;
+        }
+        // `while rollsum < cumsum && j < len { rollsum += sq[j]; j += 1 }` walks the same partial sums again: it passes
+        // every piece whose last partial sum is still below the threshold and stops inside the first other one, so only
+        // that piece has to be walked (and fetched: white noise crosses in the last piece in every lane)
+        const float thr = cumsum * 0.95f;
+        int pc = 0;
+        float rollsum = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+            if (upto[p] < thr && pc == p) { pc = p + 1; rollsum = upto[p]; }
+        int j = 64 * pc;
+        for (int p = 0; p < 4; p++) {
+            if (!__any(pc == p && rollsum < thr)) continue;
+            load_piece(p);
+            if (pc == p) {
+#pragma unroll 16
+                for (int q = 0; q < 64; q++) {
+                    const bool go = rollsum < thr;  // monotone: once false it stays false
+                    rollsum = go ? rollsum + row[q] * row[q] : rollsum;
+                    j += go ? 1 : 0;
+                }
+            }
+        }
+        const float bins = cumsum != 0.0f ? (float)j : 0.0f;
+        if (base + lane < n) rolloff[frame[base + lane]] = freq_per_bin * fmaxf(bins, 0.0f);
+    }
+}
+
+void launch_rolloff_fix(const Batch& b, const Workspace& w, uint64_t total_t, hipStream_t st) {
+    if (b.tiles_f == 0) return;
+    // a grid for 1/16 of the frames (a few per cent reach this pass); the loop covers whatever arrived
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(1u << 20, total_t / (16 * 64) + 1);
+    hipLaunchKernelGGL(rolloff_fix_kernel, dim3(blocks), dim3(64), 0, st, w.roll_fix, w.rolloff);
+}
+
 void launch_summary(const Batch& b, const Workspace& w, hipStream_t st) {
     if (b.n_songs == 0) return;
     hipLaunchKernelGGL(summary_kernel, dim3((b.n_songs + 63) / 64, R_COUNT), dim3(64), 0, st, b.songs, b.n_songs, w.centroid,

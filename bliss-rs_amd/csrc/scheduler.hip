@@ -79,10 +79,19 @@ Workspace carve(uint8_t* base, uint32_t ns, const ChunkTotals& t, size_t* bytes)
     w.centroid = m.take<float>(t.tot_t); w.rolloff = m.take<float>(t.tot_t); w.flatness = m.take<float>(t.tot_t);
     w.flux = m.take<float>(t.tot_b); w.thresholded = m.take<float>(t.tot_b);
     w.e256 = m.take<float>(t.tot_e); w.zc256 = m.take<uint32_t>(t.tot_e);
-    w.spec = m.take<float>(t.tot_c * CBINS_PAD + 64); w.frame_max = m.take<float>(t.tot_c);
+    // The spectrogram and the peak records -- both first written by the FFT-8192 kernel -- lie back to back: until that
+    // kernel starts, the FFT-512 kernel's unproven-rolloff frames borrow the stretch (257 words per entry; consumed by
+    // rolloff_fix_kernel).  18 412 bytes per chroma frame = 17.9 entries per 2205 samples, and a song has one timbral frame
+    // per 128 samples (17.2 per 2205): EVERY frame of the chunk would fit, so no entry is ever turned away.
+    w.spec = m.take<float>(t.tot_c * CBINS_PAD + 64);
+    w.peak_rec = m.take<uint32_t>(t.tot_c * PIP_MAX_PER_FRAME);
+    w.roll_fix_bytes = (size_t)(reinterpret_cast<uint8_t*>(w.peak_rec + t.tot_c * PIP_MAX_PER_FRAME) - reinterpret_cast<uint8_t*>(w.spec));
+    w.frame_max = m.take<float>(t.tot_c);
+    w.roll_fix = m.take<RollFix>(1);
+    w.roll_fix_cursor = m.take<uint32_t>(4);
     w.h1 = m.take<uint32_t>((size_t)ns * H1_BINS); w.hist100 = m.take<uint32_t>((size_t)ns * N_TUNING);
     w.tuning = m.take<TuningState>(ns);
-    w.peak_rec = m.take<uint32_t>(t.tot_c * PIP_MAX_PER_FRAME); w.peak_cnt = m.take<uint32_t>(t.tot_c);
+    w.peak_cnt = m.take<uint32_t>(t.tot_c);
     w.cand_mag = m.take<double>(t.cand_cap); w.cand_pb = m.take<uint8_t>(t.cand_cap);
     w.cand_cursor = m.take<uint32_t>(4);
     w.cand_cap = (uint32_t)t.cand_cap;
@@ -140,7 +149,7 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
     t.cand_cap = std::min<uint64_t>(t.tot_c * (uint64_t)c->cand_budget, 0xFFFFFF00ull) + 64;
 
     // ---- buffers of the slot (growth frees the old block, which waits for the device) ----
-    const size_t desc_bytes = align_up(ns * sizeof(SongDesc), 256) + 4 * align_up((ns + 1) * 4, 256);
+    const size_t desc_bytes = align_up(ns * sizeof(SongDesc), 256) + 4 * align_up((ns + 1) * 4, 256) + 256;
     size_t need = 0;
     (void)carve(nullptr, ns, t, &need);
     if ((rc = slot.desc.ensure(desc_bytes))) return rc;
@@ -161,7 +170,6 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
     const size_t o_ct = o; memcpy(h + o, pfx_ct.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
     const size_t o_cw = o; memcpy(h + o, pfx_cw.data(), (ns + 1) * 4); o = align_up(o + (ns + 1) * 4, 256);
     HIP_TRY(hipMemcpyAsync(slot.desc.p, h, o, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(slot.ev_desc, st));
     slot.used = true;
 
     Batch& b = slot.batch;
@@ -181,11 +189,24 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
     const Workspace& w = slot.ws;
     c->last_ws = w;
     c->last_songs.assign(songs, songs + ns);
+    {
+        // the exact rolloff pass's record (its entries borrow the spectrogram + peak records, see carve)
+        RollFix rf{};
+        rf.cap = (uint32_t)std::min<uint64_t>(t.tot_t, w.roll_fix_bytes / (257 * 4));  // = tot_t (see carve)
+        rf.mags = w.spec;
+        rf.frame = reinterpret_cast<uint32_t*>(w.spec + (size_t)rf.cap * 256);
+        rf.cursor = w.roll_fix_cursor;
+        HIP_TRY(hipMemsetAsync(w.roll_fix_cursor, 0, 16, st));
+        memcpy(h + o, &rf, sizeof(rf));
+        HIP_TRY(hipMemcpyAsync(w.roll_fix, h + o, sizeof(rf), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipEventRecord(slot.ev_desc, st));
 
     HIP_TRY(hipMemsetAsync(w.h1, 0, (size_t)ns * H1_BINS * 4, st));
     HIP_TRY(hipMemsetAsync(w.hist100, 0, (size_t)ns * N_TUNING * 4, st));
     HIP_TRY(hipMemsetAsync(w.cand_cursor, 0, 16, st));
-    { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st); }
+    { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st, c->rolloff_exact_all); }
+    { Prof p(c, K_ROLLFIX); launch_rolloff_fix(b, w, t.tot_t, st); }
     { Prof p(c, K_ONSET); launch_onset(b, w, st); }
     // tails: the reference runs them as the tempo / timbral / loudness threads of src/song/mod.rs:432-491
     if (multi) {

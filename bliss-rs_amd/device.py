@@ -59,7 +59,7 @@ class Context:
         _ffi.check(self._L.blissgpu_ctx_synchronize(self._h))
 
     OPTIONS = {"serial": _ffi.OPT_SERIAL, "tail_mode": _ffi.OPT_TAIL_MODE, "pipeline_chunks": _ffi.OPT_PIPELINE_CHUNKS,
-               "cand_budget": _ffi.OPT_CAND_BUDGET}
+               "cand_budget": _ffi.OPT_CAND_BUDGET, "rolloff_exact_all": _ffi.OPT_ROLLOFF_EXACT_ALL}
 
     def set_option(self, name: str, value: int):
         """Scheduling knobs for the measurement tools and the tests (blissgpu_ctx_set_option)."""

@@ -88,6 +88,8 @@ int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
 #define BLISSGPU_OPT_TAIL_MODE 1        /* beat tracker: -1 auto (default), 0 beside / 1 behind the FFT-8192 kernel */
 #define BLISSGPU_OPT_PIPELINE_CHUNKS 2  /* cut big batches into at least this many chunks (default 1) */
 #define BLISSGPU_OPT_CAND_BUDGET 3      /* tuning-candidate pool: slots per chroma frame (default 48; 0 starves the pool) */
+#define BLISSGPU_OPT_ROLLOFF_EXACT_ALL 4 /* 1: every frame's rolloff bin through the reference-order pass, not only the frames
+                                           the FFT-512 kernel cannot prove (tests: both must give the same rows) */
 int blissgpu_ctx_set_option(blissgpu_ctx *ctx, int option, int64_t value);
 
 /* The default contexts: how many there are, the HIP ordinal of the k-th, and how many coalesced batches of single-song

@@ -496,3 +496,52 @@ def test_two_hour_song_vs_oracle(bliss, oracle):
     c.synchronize()
     assert np.array_equal(alone.cpu().numpy()[0], got[0])
     c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# spectral rolloff is a bin COUNT: discontinuous in the sums it is derived from.  The FFT-512 kernel sums in its own order
+# and hands every frame it cannot prove (a running energy within worst-case rounding of the 95 % threshold) to
+# rolloff_fix_kernel, which repeats the reference's loop (src/aubio.rs:36-58) literally.
+# ---------------------------------------------------------------------------------------------
+def _musical_songs(oracle, n, seed):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import musical_check
+
+    rng = np.random.default_rng(seed)
+    return [musical_check.make_song(rng)[0] for _ in range(n)] + [oracle.white_noise(700 + i, 45 * 22050) for i in range(6)]
+
+
+def test_rolloff_bins_follow_the_reference_order(bliss, oracle):
+    """Per-frame rolloff against the oracle on random musical signals (detuned notes, bursts, noise floors: spectra with
+    plateaus, where a flipped decision moves the bin by the distance between two partials) and white noise.  What is left
+    is the oracle's own sensitivity to FFT rounding: 10 frames in 1.84 million between its f32 and f64 transforms; the
+    kernel's own summation order alone gave 168 (tests/tools/rolloff_flips.py)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    songs = _musical_songs(oracle, 60, 2)
+    c = bliss.Context(0)
+    _run(c, songs, 2)
+    gpu = [c.debug_fetch("rolloff", i) for i in range(len(songs))]
+    with ThreadPoolExecutor(32) as ex:
+        ref = list(ex.map(lambda x: oracle.SpectralDesc().run(x).series()[1], songs))
+    frames = sum(len(r) for r in ref)
+    flips = sum(int((np.abs(g - r) > 1e-3).sum()) for g, r in zip(gpu, ref))
+    print(f"rolloff: {flips} of {frames} frames differ from the oracle")
+    assert frames > 350000 and flips <= 8, (flips, frames)     # the kernel's order alone: ~ 35 on these songs
+    c.close()
+
+
+def test_rolloff_guard_agrees_with_the_exact_pass(bliss, oracle):
+    """Every frame through the reference-order pass (a test option) must give the rows and the per-frame series the
+    guarded kernel gives: the guard's proof, checked on ~ 1.2 million frames of musical signals and white noise."""
+    songs = _musical_songs(oracle, 40, 5) + [oracle.white_noise(800 + i, 180 * 22050) for i in range(24)]
+    c = bliss.Context(0)
+    rows, _ = _run(c, songs, 2)
+    series = [c.debug_fetch("rolloff", i) for i in range(len(songs))]
+    c.set_option("rolloff_exact_all", 1)
+    rows_all, _ = _run(c, songs, 2)
+    series_all = [c.debug_fetch("rolloff", i) for i in range(len(songs))]
+    assert sum(len(s) for s in series) > 1000000
+    assert all(np.array_equal(a, b) for a, b in zip(series, series_all))
+    assert np.array_equal(rows, rows_all)
+    c.close()

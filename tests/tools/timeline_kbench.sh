@@ -11,7 +11,9 @@ import csv, glob, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((r["Kernel_Name"].split("(")[0].replace("bg::", "")[:26], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        # "void bg::fft512_kernel<false>(float const*, ...)" -> "fft512_kernel"
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bg::", "").split("<")[0]
+        rows.append((name[:26], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 rows.sort(key=lambda r: r[1])
 # the last step = from the last launch of the first big kernel of a step
 firsts = [i for i, r in enumerate(rows) if r[0] in ("fft512_kernel", "stft8192_kernel")]
