@@ -20,7 +20,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 SR = 22050
 
 
-def make_song(rng):
+def make_song(rng, mods=False):
     seconds = float(rng.uniform(12.0, 60.0))
     n = int(seconds * SR) + int(rng.integers(0, 2205))
     t = np.arange(n) / SR
@@ -62,7 +62,29 @@ def make_song(rng):
             t0 = k * beat + (swing * beat if k % 2 else 0.0)
     x += rng.standard_normal(n) * (0.05 if kind == 3 else float(rng.choice([0.0, 1e-4, 3e-3])))
     x *= 10.0 ** float(rng.uniform(-3.0, 0.0)) / max(1e-9, np.abs(x).max())
-    return x.astype(np.float32), {"kind": kind, "cents": round(cents, 2), "bpm": round(bpm, 2), "seconds": round(seconds, 2)}
+    meta = {"kind": kind, "cents": round(cents, 2), "bpm": round(bpm, 2), "seconds": round(seconds, 2)}
+    if mods:
+        # what recordings do to the paths white noise never enters: stretches of digital silence (the beat tracker's
+        # silence gate, zero-energy frames), a DC offset (zero crossings, energies), a fade, a song barely long enough
+        m = []
+        if rng.random() < 0.3:
+            for _ in range(int(rng.integers(1, 4))):
+                a = int(rng.uniform(0.0, max(0.1, seconds - 3.0)) * SR)
+                x[a:a + int(rng.uniform(0.3, 3.0) * SR)] = 0.0
+            m.append("gaps")
+        if rng.random() < 0.2:
+            x += float(rng.uniform(-0.05, 0.05)) * np.abs(x).max()
+            m.append("dc")
+        if rng.random() < 0.2:
+            k = int(rng.uniform(1.0, 8.0) * SR)
+            x[:k] *= np.linspace(0.0, 1.0, k) ** 2
+            x[-k:] *= np.linspace(1.0, 0.0, k) ** 2
+            m.append("fade")
+        if rng.random() < 0.1:
+            x = x[:int(rng.integers(8192, 40000))]
+            m.append("short")
+        meta["mods"] = "+".join(m)
+    return x.astype(np.float32), meta
 
 
 def main():
@@ -70,6 +92,7 @@ def main():
     ap.add_argument("--songs", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--threads", type=int, default=64)
+    ap.add_argument("--mods", action="store_true", help="silent gaps, DC offsets, fades, barely-long-enough songs on top")
     args = ap.parse_args()
     import torch
 
@@ -77,7 +100,7 @@ def main():
     import oracle as O
 
     rng = np.random.default_rng(args.seed)
-    songs, meta = zip(*(make_song(rng) for _ in range(args.songs)))
+    songs, meta = zip(*(make_song(rng, args.mods) for _ in range(args.songs)))
     lens = np.array([len(s) for s in songs], np.uint64)
     padded = (lens + np.uint64(63)) // np.uint64(64) * np.uint64(64)
     offs = np.zeros(len(songs), np.uint64)
@@ -118,7 +141,7 @@ def main():
     feat_over = sorted({int(j) + 1 for i in over for j in np.nonzero(err[i, 1:] > tol[i, 1:])[0]})
     tun_bad = np.nonzero(np.abs(tuning - otuning) > 1e-12)[0]
     print(json.dumps({
-        "seed": args.seed, "songs": len(songs), "seconds_of_audio": round(float(lens.sum()) / SR, 1),
+        "seed": args.seed, "mods": bool(args.mods), "songs": len(songs), "seconds_of_audio": round(float(lens.sum()) / SR, 1),
         "oracle_seconds": round(time.perf_counter() - t0, 1),
         "kinds": {str(k): int(sum(m["kind"] == k for m in meta)) for k in range(4)},
         "distinct_tunings": int(len(set(np.round(otuning, 2)))),
