@@ -27,7 +27,15 @@ constexpr int N_TUNING = 100;             // pitch_tuning histogram bins at reso
 constexpr int PIP_LO = 57, PIP_HI = 1483; // centre bins visited by pip_track at n_fft=8192 (chroma.rs:302-313)
 constexpr int PIP_MAX_PER_FRAME = 714;    // peaks cannot be adjacent: ceil(1427/2)
 constexpr int CAND_BUDGET_PER_FRAME = 48; // tuning-candidate pool of a chunk: slots per chroma frame (white noise needs ~8; see tune_select_kernel)
-constexpr int H1_BINS = 8192;             // coarse magnitude histogram: f32 bit pattern >> 18
+// Coarse magnitude histogram of the tuning estimate: bin = f32 bit pattern >> COARSE_SHIFT, i.e. 2^(23 - COARSE_SHIFT) bins
+// per octave.  64 per octave: the peaks that share the median's bins -- the candidates tune_pass2_kernel must evaluate in
+// f64 from the spectrogram -- are half as many as with 32 (2.2 % of all peaks), and 14 bits are what a 32-bit peak record
+// has left beside the centre bin and the pitch bin.
+#ifndef COARSE_SHIFT
+#define COARSE_SHIFT 17
+#endif
+constexpr uint32_t COARSE_LOW_MASK = (1u << COARSE_SHIFT) - 1u;
+constexpr int H1_BINS = 1 << (31 - COARSE_SHIFT);   // every positive f32 has a bin
 constexpr int BT_WINLEN = 512, BT_STEP = 128, BT_LAGLEN = 128;  // src/aubio.rs:1337-1341, 920-922
 constexpr int BT_PRE_STRIDE = 264;  // floats per beat-tracker run written by beat_acf_kernel (kernels_tempo.hip)
 constexpr int F512_TILE = 512;            // FFT-512 frames per workgroup (16 lane-groups x 32 consecutive frames + 1 halo frame each)

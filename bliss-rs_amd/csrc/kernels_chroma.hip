@@ -147,7 +147,7 @@ __device__ __forceinline__ int pitch_bin(double pitch) {
 }
 
 __device__ __forceinline__ uint32_t coarse_bin(double mag) {
-    const uint32_t b = __float_as_uint((float)mag) >> 18;  // monotone in mag for mag > 0
+    const uint32_t b = __float_as_uint((float)mag) >> COARSE_SHIFT;  // monotone in mag for mag > 0
     return b < (uint32_t)H1_BINS ? b : (uint32_t)H1_BINS - 1;
 }
 
@@ -162,15 +162,15 @@ __device__ __forceinline__ float ref_floor_f32(double ref) {
 // (sa <= se, sb < se) the f32 evaluation below is within 2 ulp(se) of the f64 magnitude: |avg| <= den / 2
 // bounds the interpolation term by se / 4 and its error by ~0.5 ulp(se), den > 0 is never rounded to zero
 // (2 se - sa >= se > sb), plus two final roundings.  A 16-ulp guard band around the coarse-bin edges
-// (2^18 ulp apart) therefore makes the f32 bin provably equal to coarse_bin() of the f64 magnitude;
+// (2^COARSE_SHIFT ulp apart) therefore makes the f32 bin provably equal to coarse_bin() of the f64 magnitude;
 // the ~1e-4 of peaks inside the band take the f64 path.
 __device__ __forceinline__ uint32_t peak_coarse_bin(float sb, float se, float sa, double ref, int c) {
     const float avg = 0.5f * (sa - sb);
     const float den = (2.0f * se - sa) - sb;
     const float shift = avg * __builtin_amdgcn_rcpf(den);
-    const uint32_t bits = __float_as_uint(se + (0.5f * avg) * shift), low = bits & 0x3FFFFu;
-    if (se >= 1e-30f && low >= 16u && low <= 0x3FFFFu - 16u) {
-        const uint32_t b = bits >> 18;
+    const uint32_t bits = __float_as_uint(se + (0.5f * avg) * shift), low = bits & COARSE_LOW_MASK;
+    if (se >= 1e-30f && low >= 16u && low <= COARSE_LOW_MASK - 16u) {
+        const uint32_t b = bits >> COARSE_SHIFT;
         return b < (uint32_t)H1_BINS ? b : (uint32_t)H1_BINS - 1;
     }
     double mag;
@@ -232,16 +232,16 @@ __device__ __forceinline__ uint32_t peak_classify(float sb, float se, float sa, 
     }
     *pitch_bin_out = pb;
     // coarse bin
-    const uint32_t bits = __float_as_uint(se + (0.5f * avg) * shift), low = bits & 0x3FFFFu;
-    if (normal && low >= 16u && low <= 0x3FFFFu - 16u) {
-        const uint32_t b = bits >> 18;
+    const uint32_t bits = __float_as_uint(se + (0.5f * avg) * shift), low = bits & COARSE_LOW_MASK;
+    if (normal && low >= 16u && low <= COARSE_LOW_MASK - 16u) {
+        const uint32_t b = bits >> COARSE_SHIFT;
         return b < (uint32_t)H1_BINS ? b : (uint32_t)H1_BINS - 1;
     }
     return coarse_bin_exact(sb, se, sa, ref, c);
 }
 
 // One 32-bit record per peak, written by the STFT kernel while the frame is still in LDS and consumed by tuning
-// pass 2 (which then never re-scans the spectrogram): exact coarse magnitude bin (13 bits) | pitch-residue bin + 1
+// pass 2 (which then never re-scans the spectrogram): exact coarse magnitude bin (14 bits) | pitch-residue bin + 1
 // (7 bits, 0 = the f32 evaluation was not provable, take the f64 path) | centre bin (11 bits).
 __device__ __forceinline__ uint32_t peak_record(uint32_t coarse, int pitch_bin_or_neg, int c) {
     return (coarse << 18) | ((uint32_t)(pitch_bin_or_neg + 1) << 11) | (uint32_t)c;
@@ -258,7 +258,7 @@ __device__ __forceinline__ uint32_t peak_record(uint32_t coarse, int pitch_bin_o
 // ------------------------------------------------------------------------------------------------
 constexpr int STFT_FRAMES_PER_WG = STFT_TILE;
 constexpr int STFT_GROUP = 4;     // workgroups that share a super-tile of STFT_GROUP * STFT_TILE frames, one frame in four each
-constexpr int LHIST_BINS = 512;  // 16 octaves of 32 coarse bins
+constexpr int LHIST_BINS = 512;  // 8 octaves of 64 coarse bins
 constexpr int EX1_PITCH = 257;   // k1-major rows of 256 (+1): the 16 lanes of a ds_read2_b64 group tile all 32 banks
 constexpr int EX2_PITCH = 272;   // j1-major rows of 256 (+16): shifts odd rows by 32 banks
 constexpr int STFT_LDS = 16 * EX2_PITCH;  // float2 elements (34 816 B)
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
     __shared__ f2 lds[STFT_LDS];
     __shared__ float red[4];
     // peaks are first counted in an LDS window of the coarse-magnitude histogram (a frame's peaks lie
-    // within [0.1 max, ~max], i.e. ~110 coarse bins) and flushed once per workgroup: global atomics on
+    // within [0.1 max, ~max], i.e. ~220 coarse bins) and flushed once per workgroup: global atomics on
     // a song's few hot histogram lines would otherwise serialise at the L2
     __shared__ uint32_t lhist[LHIST_BINS];
     __shared__ uint32_t lhist_base;
