@@ -201,7 +201,8 @@ __global__ __launch_bounds__(64) void rolloff_fix_kernel(const RollFix* __restri
     // One wavefront per 64 frames, a lane per frame.  A frame's 256 magnitudes are 1 KB apart from its neighbour's: they
     // are fetched with coalesced 16-byte loads (four frames x 256 B per instruction) into a padded LDS tile, 64 bins of all
     // 64 frames at a time, and every lane then walks its own row.  (Keeping all 256 bins of the 64 frames in LDS -- one
-    // read instead of two -- leaves two wavefronts per CU and takes twice as long: 0.47 vs 0.23 ms per 512 songs.)
+    // read instead of two -- leaves two wavefronts per CU and takes twice as long; 16 whole frames per pass, read once
+    // and contiguously, with 16 walking lanes is slower as well.)
     __shared__ float tile[64 * 65];
     const uint32_t n = min(fix->cursor[0], fix->cap);
     const float* __restrict__ mags = fix->mags;
@@ -211,13 +212,19 @@ __global__ __launch_bounds__(64) void rolloff_fix_kernel(const RollFix* __restri
     for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {
         auto load_piece = [&](int p) {
             __syncthreads();
-#pragma unroll 4
+            // all 16 loads of the piece in flight together: the wavefront pays the memory latency once per piece (with four
+            // at a time the kernel took 0.25 instead of 0.1 ms per 1024 songs -- the latency, not the walks, was the wait)
+            float4 v[16];
+#pragma unroll
             for (uint32_t q = 0; q < 16; q++) {
                 const uint32_t e = 4 * q + (lane >> 4), f4 = lane & 15;
-                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (base + e < n) v = *reinterpret_cast<const float4*>(mags + (size_t)(base + e) * 256 + 64 * p + 4 * f4);
-                float* t = tile + e * 65 + 4 * f4;
-                t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+                v[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (base + e < n) v[q] = *reinterpret_cast<const float4*>(mags + (size_t)(base + e) * 256 + 64 * p + 4 * f4);
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 16; q++) {
+                float* t = tile + (4 * q + (lane >> 4)) * 65 + 4 * (lane & 15);
+                t[0] = v[q].x; t[1] = v[q].y; t[2] = v[q].z; t[3] = v[q].w;
             }
             __syncthreads();
         };
