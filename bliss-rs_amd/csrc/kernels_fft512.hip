@@ -209,6 +209,8 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
                                                         float* __restrict__ e256, uint32_t* __restrict__ zc256,
                                                         const RollFix* __restrict__ fix) {
     __shared__ f2 lds[GROUPS_PER_WG * GRP_PITCH];
+    // magnitudes of every group's FIRST tempo frame, for the group before it (see `share` below)
+    __shared__ float halo[GROUPS_PER_WG][16 * 16 + 1];
     RegTables tabs;
     {
         const int l0 = threadIdx.x & 15;
@@ -243,8 +245,14 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
     FrameMags A, B;
     const bool active = k_begin < (long)sd.n_f;
     f2 raw[16];
+    // The flux of a group's first tempo frame (FFT frame k_begin + 1) needs the magnitudes of the tempo frame before it,
+    // FFT frame k_begin - 1 -- the last frame of the group before.  Only the first group of a workgroup transforms that
+    // halo frame itself (33 transforms for 32 frames); the other fifteen publish the magnitudes of their first tempo
+    // frame in LDS and leave that one flux value to their predecessor, which has frame k_begin - 1 in registers when its
+    // loop ends.  Same operands, same order of additions: the series is bit-identical.
+    const bool share = active && grp > 0;
     // halo: magnitudes of the previous tempo frame (FFT frame k_begin - 1); zeros before the song starts
-    if (active && k_begin >= 1) {
+    if (active && k_begin >= 1 && !share) {
         fft512_load(r_x, k_begin * HOP_T - W512 - base, l, raw);
         fft512_compute<0>(raw, l, tile, tabs, A);
     } else {
@@ -292,7 +300,14 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
                 if (cur.m[e] > prev.m[e]) f += cur.m[e] - prev.m[e];
             if (l == 0 && cur.nyq > prev.nyq) f += cur.nyq - prev.nyq;
             f = row16_sum(f);
-            if (l == 0 && q < (long)sd.n_b) flux[sd.b_off + q] = f;
+            if (J == 1 && share && k == k_begin + 1) {
+                // no previous tempo frame here: hand this frame's magnitudes to the group before
+#pragma unroll
+                for (int e = 0; e < 16; e++) halo[grp][16 * e + l] = cur.m[e];
+                if (l == 0) halo[grp][256] = cur.nyq;
+            } else if (l == 0 && q < (long)sd.n_b) {
+                flux[sd.b_off + q] = f;
+            }
         }
         if (k < (long)sd.n_t) {
             // the 256-bin vector the reference's timbral path sees: bin 255 := |Re X[256]| (src/aubio.rs:240-261)
@@ -418,6 +433,23 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
         if (kb + 3 < k_end) frame(std::integral_constant<int, 3>{}, kb + 3, A, B);
         __builtin_amdgcn_sched_barrier(0);
         if ((kb & 15) == 12 || kb + 4 >= k_end) finish16(kb & ~15L);  // 16 frames stashed, or the group's last frames
+    }
+
+    // ---- the flux of the NEXT group's first tempo frame (FFT frame k_begin + 33) against this group's last one (k_begin +
+    // 31, in set A when the loop has run its 32 frames) ----
+    __syncthreads();
+    if (grp + 1 < GROUPS_PER_WG && k_begin + FRAMES_PER_GROUP + 1 < (long)sd.n_f) {
+        const long q = (k_begin + FRAMES_PER_GROUP) >> 1;
+        float f = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const float c = halo[grp + 1][16 * e + l];
+            if (c > A.m[e]) f += c - A.m[e];
+        }
+        const float cn = halo[grp + 1][256];
+        if (l == 0 && cn > A.nyq) f += cn - A.nyq;
+        f = row16_sum(f);
+        if (l == 0 && q < (long)sd.n_b) flux[sd.b_off + q] = f;
     }
 
     // ---- the samples no FFT frame brings in: [128 n_f, n), 256 .. 511 of them, handled by the group that owns the

@@ -495,11 +495,23 @@ int submit(AnalyzeReq& r, const char* who) {
         // The callers the previous batch released are on their way back with their next song: when that batch showed
         // there is company, give them a moment (at most 200 us against a batch of milliseconds) instead of running a
         // batch of one.  A lone caller never waits.
-        if (g_seat_last_batch[seat] > 1)
+        const bool waited = g_seat_last_batch[seat] > 1;  // the mutex was released while this thread held the seat
+        if (waited)
             g_cv_arrive.wait_for(lk, std::chrono::microseconds(200), [&] { return g_queue.size() >= g_seat_last_batch[seat]; });
         std::vector<AnalyzeReq*> take;
         take.swap(g_queue);
-        if (!take.empty()) {  // (empty: another leader took everything, this caller's request included, during the wait)
+        if (take.empty()) {
+            // Another leader took everything, this caller's request included, while this thread was waiting (for a seat or
+            // for company).  Give the seat back and SLEEP until that leader reports: going round again at once would spin
+            // with the mutex held -- no wait in the loop when the seat's last batch was a single song -- and the leader
+            // that holds this request could never lock it to mark the request done (seen once as a hung 16-thread run
+            // with two seats; with one seat the only leader always finds its own request in the queue).
+            g_seat_taken[seat] = 0;
+            if (waited) g_cv_done.notify_all();  // someone may have found no seat free meanwhile
+            g_cv_done.wait(lk);
+            continue;
+        }
+        {
             g_seat_last_batch[seat] = take.size();
             lk.unlock();
             // No exception may strand the followers (their `done` flags) or keep the seat: a failed allocation while

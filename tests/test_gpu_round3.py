@@ -158,7 +158,7 @@ def _kv(stdout):
 def test_single_song_front_spreads_over_two_default_contexts(tmp_path):
     exe = _threads_exe(tmp_path)
     env = dict(os.environ, BLISSGPU_DEFAULT_DEVICES="0,0")
-    out = subprocess.run([str(exe), "16", "32"], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([str(exe), "16", "32"], capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout          # every threaded row bit-identical to the serial run
     kv = _kv(out.stdout)
@@ -166,6 +166,19 @@ def test_single_song_front_spreads_over_two_default_contexts(tmp_path):
     assert kv["default_device_0_hip_ordinal"] == "0" and kv["default_device_1_hip_ordinal"] == "0"
     assert int(kv["default_device_0_batches"]) > 0 and int(kv["default_device_1_batches"]) > 0, out.stdout
     print(out.stdout)
+
+
+@pytest.mark.parametrize("seats", [4, 8])
+def test_single_song_front_with_many_seats_does_not_stall(tmp_path, seats):
+    """More seats than one (an 8-GPU node has eight): a caller whose request was taken along by ANOTHER leader while it
+    waited must sleep until that leader reports -- it used to go round again with the mutex held, and the leader could
+    never mark the request done (one hung run of the two-seat test).  32 threads x 16 calls, three times over."""
+    exe = _threads_exe(tmp_path)
+    env = dict(os.environ, BLISSGPU_DEFAULT_DEVICES=",".join(["0"] * seats))
+    for _ in range(3):
+        out = subprocess.run([str(exe), "32", "16"], capture_output=True, text=True, timeout=120, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "all checks passed" in out.stdout and _kv(out.stdout)["default_devices"] == str(seats)
 
 
 def test_default_contexts_follow_the_visible_devices(tmp_path, bliss):
