@@ -19,6 +19,7 @@
 #include <condition_variable>
 #include <numeric>
 
+#include "coalescing_front.hpp"
 #include "ctx.hpp"
 
 using namespace bg;
@@ -430,17 +431,9 @@ struct AnalyzeReq {
     bool done = false;
 };
 
-// One mutex, two condition variables: `arrive` wakes a leader that is gathering its batch, `done` wakes the callers whose
-// requests a leader has finished -- and the callers waiting for a free device.  There is one leader seat per default
-// context (= per visible device): whoever finds a seat free takes it and the whole queue with it, so on an 8-GPU node
-// the N worker threads of the reference's bulk path (src/song/decoder.rs:299-329) keep all eight devices busy, each
-// batch going to the device whose previous batch finished first.  The lowest free seat is taken, so a lone caller
-// always lands on the first device (whose context is warm).
-std::mutex g_mu;
-std::condition_variable g_cv_arrive, g_cv_done;
-std::vector<AnalyzeReq*> g_queue;
-std::vector<char> g_seat_taken;
-std::vector<size_t> g_seat_last_batch;
+// The queue, the seats and the waiting are in coalescing_front.hpp (device-free: tests/cpp/test_front.cpp drives it on the
+// CPU); a leader's batch runs on the default context of its seat.
+bg::CoalescingFront<AnalyzeReq> g_front;
 
 void run_batch(std::vector<AnalyzeReq*>& take, int seat, const char* who) {
     blissgpu_ctx* c = nullptr;
@@ -478,56 +471,14 @@ void run_batch(std::vector<AnalyzeReq*>& take, int seat, const char* who) {
 }
 
 int submit(AnalyzeReq& r, const char* who) {
-    const int n_seats = default_ctx_count();
-    std::unique_lock<std::mutex> lk(g_mu);
-    if (g_seat_taken.empty()) { g_seat_taken.assign(n_seats, 0); g_seat_last_batch.assign(n_seats, 1); }
-    g_queue.push_back(&r);
-    g_cv_arrive.notify_one();
-    while (!r.done) {
-        int seat = -1;
-        for (int k = 0; k < n_seats && seat < 0; k++)
-            if (!g_seat_taken[k]) seat = k;
-        if (seat < 0) {  // every device is running a batch: the next leader will take this request along
-            g_cv_done.wait(lk);
-            continue;
+    g_front.submit(r, default_ctx_count(), [&](std::vector<AnalyzeReq*>& take, int seat) {
+        // a failed allocation while gathering the batch becomes an error code on every request of the batch
+        try {
+            run_batch(take, seat, who);
+        } catch (...) {
+            for (AnalyzeReq* t : take) { t->rc = BLISSGPU_ERR_OOM; t->err = "out of host memory while gathering the batch"; }
         }
-        g_seat_taken[seat] = 1;
-        // The callers the previous batch released are on their way back with their next song: when that batch showed
-        // there is company, give them a moment (at most 200 us against a batch of milliseconds) instead of running a
-        // batch of one.  A lone caller never waits.
-        const bool waited = g_seat_last_batch[seat] > 1;  // the mutex was released while this thread held the seat
-        if (waited)
-            g_cv_arrive.wait_for(lk, std::chrono::microseconds(200), [&] { return g_queue.size() >= g_seat_last_batch[seat]; });
-        std::vector<AnalyzeReq*> take;
-        take.swap(g_queue);
-        if (take.empty()) {
-            // Another leader took everything, this caller's request included, while this thread was waiting (for a seat or
-            // for company).  Give the seat back and SLEEP until that leader reports: going round again at once would spin
-            // with the mutex held -- no wait in the loop when the seat's last batch was a single song -- and the leader
-            // that holds this request could never lock it to mark the request done (seen once as a hung 16-thread run
-            // with two seats; with one seat the only leader always finds its own request in the queue).
-            g_seat_taken[seat] = 0;
-            if (waited) g_cv_done.notify_all();  // someone may have found no seat free meanwhile
-            g_cv_done.wait(lk);
-            continue;
-        }
-        {
-            g_seat_last_batch[seat] = take.size();
-            lk.unlock();
-            // No exception may strand the followers (their `done` flags) or keep the seat: a failed allocation while
-            // gathering the batch becomes an error code on every request of the batch.
-            try {
-                run_batch(take, seat, who);
-            } catch (...) {
-                for (AnalyzeReq* t : take) { t->rc = BLISSGPU_ERR_OOM; t->err = "out of host memory while gathering the batch"; }
-            }
-            lk.lock();
-            for (AnalyzeReq* t : take) t->done = true;
-        }
-        g_seat_taken[seat] = 0;
-        g_cv_done.notify_all();
-    }
-    lk.unlock();
+    });
     if (r.rc) return fail(r.rc, who, r.err.c_str());
     return BLISSGPU_OK;
 }

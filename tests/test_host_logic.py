@@ -288,3 +288,16 @@ print(n, [L.blissgpu_default_device(k) for k in range(n)], L.blissgpu_default_de
         env = {k: v for k, v in os.environ.items() if k != "BLISSGPU_DEFAULT_DEVICES"}
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
         assert out.stdout.strip() == "1 [0] -1 -1", out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("seats", [1, 2, 8])
+def test_coalescing_front_on_the_cpu(tmp_path, seats):
+    """The group-commit front of the single-song entry points (bliss-rs_amd/csrc/coalescing_front.hpp) is device-free:
+    32 threads x 1500 calls against 1 / 2 / 8 seats with a batch runner that sleeps.  Every request runs exactly once, no
+    seat runs two batches at a time, several seats are used -- and the run ends: with more than one seat the first form of
+    this loop could spin with the mutex held when another leader had taken a caller's request along (a hung -m gpu run)."""
+    exe = tmp_path / "test_front"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_front.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe), "32", "1500", str(seats), "300"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "bad 0" in out.stdout and f"of {seats}" in out.stdout
