@@ -84,6 +84,9 @@ Workspace carve(uint8_t* base, uint32_t ns, const ChunkTotals& t, size_t* bytes)
     // kernel starts, the FFT-512 kernel's unproven-rolloff frames borrow the stretch (257 words per entry; consumed by
     // rolloff_fix_kernel).  18 412 bytes per chroma frame = 17.9 entries per 2205 samples, and a song has one timbral frame
     // per 128 samples (17.2 per 2205): EVERY frame of the chunk would fit, so no entry is ever turned away.
+    static_assert((size_t)(CBINS_PAD + PIP_MAX_PER_FRAME) * 4 * HOP_T >= (size_t)257 * 4 * HOP_C,
+                  "the borrowed stretch must hold one 257-word entry per timbral frame: bytes per chroma frame x samples per "
+                  "timbral frame >= bytes per entry x samples per chroma frame");
     w.spec = m.take<float>(t.tot_c * CBINS_PAD + 64);
     w.peak_rec = m.take<uint32_t>(t.tot_c * PIP_MAX_PER_FRAME);
     w.roll_fix_bytes = (size_t)(reinterpret_cast<uint8_t*>(w.peak_rec + t.tot_c * PIP_MAX_PER_FRAME) - reinterpret_cast<uint8_t*>(w.spec));
