@@ -301,3 +301,72 @@ def test_coalescing_front_on_the_cpu(tmp_path, seats):
     out = subprocess.run([str(exe), "32", "1500", str(seats), "300"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "bad 0" in out.stdout and f"of {seats}" in out.stdout
+
+
+def test_rolloff_guard_on_emulated_summation_orders():
+    """The FFT-512 kernel counts the rolloff bins in its own summation order and proves, per frame, that the reference's
+    sequential order (src/aubio.rs:36-58) gives the same count -- or hands the frame to the exact pass (kernels_fft512.hip,
+    the frame epilogue; ROLL_GUARD).  Here both orders are emulated in numpy f32, operation for operation (fused squares,
+    lane scan by row_shr 1/2/4/8, butterfly total, the walk as d = running - threshold), on white, pink and sparse spectra
+    and on frames ENGINEERED to sit on a tie (a partial holding 5 % of the energy within 3e-7): wherever the two orders
+    disagree the guard must have flagged the frame.  (White noise: 2 % flagged, as measured on the GPU.)"""
+    import re
+
+    src = open(os.path.join(ROOT, "bliss-rs_amd", "csrc", "kernels_fft512.hip")).read()
+    guard = np.float32(float(re.search(r"ROLL_GUARD = ([0-9.]+)f / 16777216\.0f", src).group(1)) / 16777216.0)
+    f32 = np.float32
+
+    def fma32(a, b, c):  # round_f32(a * b + c): the product of two f32 is exact in f64
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)
+
+    def both_orders(M):
+        n = len(M)
+        sq = (M * M).astype(f32)  # the reference rounds the square, then adds
+        S = np.zeros(n, f32)
+        P = np.empty((n, 256), f32)
+        for j in range(256):
+            S = (S + sq[:, j]).astype(f32)
+            P[:, j] = S
+        cnt_seq = (P < (S * f32(0.95)).astype(f32)[:, None]).sum(1)
+        L = M.reshape(n, 16, 16)  # lane l: bins 16 l .. 16 l + 15
+        qx, qy = np.zeros((n, 16), f32), np.zeros((n, 16), f32)
+        for i in range(8):
+            qx, qy = fma32(L[:, :, 2 * i], L[:, :, 2 * i], qx), fma32(L[:, :, 2 * i + 1], L[:, :, 2 * i + 1], qy)
+        sqsum = (qx + qy).astype(f32)
+        inc = sqsum.copy()
+        for d in (1, 2, 4, 8):
+            sh = np.zeros_like(inc)
+            sh[:, d:] = inc[:, :-d]
+            inc = (inc + sh).astype(f32)
+        tot, idx = sqsum.copy(), np.arange(16)
+        for perm in (idx ^ 1, idx ^ 2, (idx & 8) | (7 - (idx & 7)), 15 - idx):
+            tot = (tot + tot[:, perm]).astype(f32)
+        total = tot[:, 0]
+        d = ((inc - sqsum).astype(f32) - (total * f32(0.95)).astype(f32)[:, None]).astype(f32)
+        near, cnt = np.full((n, 16), np.inf, f32), np.zeros((n, 16), np.int64)
+        for e in range(16):
+            d = fma32(L[:, :, e], L[:, :, e], d)
+            cnt += d < 0
+            near = np.minimum(near, np.abs(d))
+        risky = ((near <= (total * guard)[:, None]).any(1) | (total < 1e-30)) & (total != 0)
+        return cnt_seq, cnt.sum(1), risky
+
+    rng = np.random.default_rng(0)
+    n = 50000
+    white = np.abs(rng.standard_normal((n, 256))).astype(f32)
+    pink = (np.abs(rng.standard_normal((n, 256))) / np.sqrt(1 + np.arange(256))).astype(f32)
+    sparse = (1e-6 * np.abs(rng.standard_normal((n, 256)))).astype(f32)
+    for _ in range(6):
+        sparse[np.arange(n), rng.integers(0, 256, n)] = rng.uniform(0.05, 1.0, n).astype(f32)
+    tie = np.zeros((n, 256), f32)
+    tie[np.arange(n), rng.integers(5, 100, n)] = 1.0
+    tie[np.arange(n), rng.integers(150, 250, n)] = (np.sqrt(0.05 / 0.95) * (1 + rng.uniform(-3e-7, 3e-7, n))).astype(f32)
+    tie += (1e-5 * np.abs(rng.standard_normal((n, 256)))).astype(f32) * (rng.random((n, 1)) < 0.5)
+    disagreements = 0
+    for name, M in (("white", white), ("pink", pink), ("sparse", sparse), ("tie", tie)):
+        cs, cg, risky = both_orders(M)
+        disagreements += int((cs != cg).sum())
+        assert not ((cs != cg) & ~risky).any(), name
+        if name == "white":
+            assert 0.01 < risky.mean() < 0.035, risky.mean()
+    assert disagreements > 20       # the engineered ties do make the orders disagree: the check is not vacuous
