@@ -46,11 +46,7 @@ __global__ __launch_bounds__(256) void chroma_bank_kernel(double* __restrict__ b
     if (k >= BANK_PITCH) return;
     double* out = bank + (size_t)slot * BANK_ROWS * BANK_PITCH;
     if (k >= CBINS) {
-#ifdef HP_CHECK_A
-        for (int r = 0; r < BANK_ROWS; r++) out[(size_t)r * BANK_PITCH + k] = (double)(r * 8192 + k);
-#else
         for (int r = 0; r < BANK_ROWS; r++) out[(size_t)r * BANK_PITCH + k] = 0.0;
-#endif
         return;
     }
     const double tuning = tuning_of_slot(slot);
@@ -78,9 +74,6 @@ __global__ __launch_bounds__(256) void chroma_bank_kernel(double* __restrict__ b
     for (int r = 0; r < BANK_ROWS; r++) {
         double v = 0.0;
         if (r < 12) v = (w[(r + 3) % 12] / l2) * g;  // np.roll(-3) along the chroma axis
-#ifdef HP_CHECK_A
-        v = (double)(r * 8192 + k);  // probe build: every filter value names its own place (see chroma_handpipe.inc)
-#endif
         out[(size_t)r * BANK_PITCH + k] = v;
     }
 }
@@ -286,16 +279,9 @@ __device__ __forceinline__ long reflect_index(long p, long n) {
     return p;
 }
 
-// Developer build (-DSTFT_TRACE): wall-clock shader cycles of wave 0 of every workgroup between the marks in the frame
-// loop, summed per mark over the launches (LDS counters, flushed once per workgroup); tests/tools/kbench prints the table.
-#ifdef STFT_TRACE
-__device__ unsigned long long g_stft_trace[32];
-#define TRACE_DECL __shared__ uint32_t trace_acc[32]; uint32_t trace_prev = 0;
-#define TRACE_INIT() do { if (threadIdx.x < 32) trace_acc[threadIdx.x] = 0; } while (0)
-#define TRACE_START() do { trace_prev = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
-#define TRACE(k) do { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&trace_acc[k], now_ - trace_prev); trace_prev = now_; } while (0)
-#define TRACE_FLUSH() do { __syncthreads(); if (threadIdx.x < 32 && trace_acc[threadIdx.x]) atomicAdd(&g_stft_trace[threadIdx.x], (unsigned long long)trace_acc[threadIdx.x]); } while (0)
-#else
+// Hooks of the per-phase cycle trace (tests/tools/probes/stft_trace/stft_trace.hip defines them and then includes this
+// file; in the library they are empty)
+#ifndef TRACE
 #define TRACE_DECL
 #define TRACE_INIT() do {} while (0)
 #define TRACE_START() do {} while (0)
@@ -303,12 +289,6 @@ __device__ unsigned long long g_stft_trace[32];
 #define TRACE_FLUSH() do {} while (0)
 #endif
 
-#ifndef STFT_STORE_POS
-#define STFT_STORE_POS 0
-#endif
-#ifndef STFT_STORE_AUX
-#define STFT_STORE_AUX 2
-#endif
 // 4 workgroups per CU: 128 VGPRs, spill-free
 __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restrict__ pcm,
                                                        const SongDesc* __restrict__ songs, uint32_t n_songs,
@@ -328,7 +308,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
     __shared__ uint32_t lhist_base;
     __shared__ uint16_t peak_list[PIP_MAX_PER_FRAME + 2];
     __shared__ uint32_t peak_count;
-    __shared__ f2 tw256[256];  // W_256^(m2*j1) at [16 j1 + m2] (pass-2 twiddles, broadcast reads)
+    __shared__ __attribute__((aligned(16))) f2 tw256[256];  // W_256^(m k) at [16 m + k]: symmetric in (m, k)
     TRACE_DECL
     TRACE_INIT();
     {
@@ -385,6 +365,14 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
     // by tests/tools/determinism_check.py; every parity test passed).
     __syncthreads();
 
+    // W_256^(m k): the table is symmetric, so the fifteen twiddles a thread needs in a pass (fixed m = t >> 4) are 128
+    // consecutive bytes, read two at a time (ds_read_b128: 4 LDS cycles per pair; two 8-byte reads a row apart are merged
+    // by hipcc into ds_read2_b64 at 8)
+    auto tw_at = [&](int m, int k) -> f2 {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 pair = reinterpret_cast<const f4*>(tw256)[8 * m + (k >> 1)];
+        return (k & 1) ? mk(pair.z, pair.w) : mk(pair.x, pair.y);
+    };
     // raw samples of one frame: z[256*n1 + t] = (x[w0 + 2n], x[w0 + 2n + 1]), reflect only at the song edges
     auto load_frame = [&](uint32_t f, f2 (&xr)[16]) {
         const long w0 = (long)f * HOP_C - W8192 / 2;
@@ -429,7 +417,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         radix16(v);
 #pragma unroll
         for (int k1 = 1; k1 < 16; k1++)
-            v[R16(k1)] = cmul_pk(v[R16(k1)], tw256[16 * k1 + hi4]);
+            v[R16(k1)] = cmul_pk(v[R16(k1)], tw_at(hi4, k1));
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) lds[k1 * EX1_PITCH + t] = v[R16(k1)];
         TRACE(0);
@@ -441,7 +429,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         radix16(v);
         v[R16(0)] = cmul_pk(v[R16(0)], c_p2);
 #pragma unroll
-        for (int j1 = 1; j1 < 16; j1++) v[R16(j1)] = cmul_pk(v[R16(j1)], cmul_pk(tw256[16 * j1 + hi4], c_p2));
+        for (int j1 = 1; j1 < 16; j1++) v[R16(j1)] = cmul_pk(v[R16(j1)], cmul_pk(tw_at(hi4, j1), c_p2));
         TRACE(2);
         __syncthreads();
         TRACE(3);
@@ -524,11 +512,11 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
                 const int q = t + 256 * i;
                 if (i < 4 || q < CBINS_PAD / 4) {
                     const u32x4_t val = i < 4 ? mags4[q] : mags4[q - 1024 + MAGS_TOP / 4];
-                    __builtin_amdgcn_raw_buffer_store_b128(val, r_row, 16u * (uint32_t)q, 0, STFT_STORE_AUX);  // nt: streamed once
+                    __builtin_amdgcn_raw_buffer_store_b128(val, r_row, 16u * (uint32_t)q, 0, 2);  // nt: streamed once
                 }
             }
         };
-        if (STFT_STORE_POS == 0) store_row();
+        store_row();
         mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         if (t == 0) frame_max[sd.c_off + f] = mx;
         if (!have_base) {  // uniform: anchor the LDS window LHIST_BINS/2 bins below the first frame's maximum
@@ -580,7 +568,6 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
 #pragma unroll
             for (int j = 0; j < 6; j++)
                 if ((hits >> j) & 1u) peak_list[pos++] = (uint16_t)(t + 256 * j);
-            if (STFT_STORE_POS == 1) store_row();
             TRACE(13);
             __syncthreads();
             TRACE(14);
@@ -601,9 +588,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
                 else atomicAdd(&hist[b], 1u);
             }
         }
-        if (STFT_STORE_POS == 2) store_row();
         __builtin_amdgcn_s_setprio(0);
-        if (STFT_STORE_POS == 3) store_row();
         if (has_next) {
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window of the next frame
@@ -623,17 +608,6 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         }
     }
 }
-
-#ifdef STFT_TRACE
-extern "C" int blissgpu_debug_stft_trace(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stft_trace), sizeof(g_stft_trace)) != hipSuccess) return 1;
-    if (reset) {
-        unsigned long long z[32] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stft_trace), z, sizeof(z)) != hipSuccess) return 1;
-    }
-    return 0;
-}
-#endif
 
 void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.tiles_c == 0) return;
@@ -661,7 +635,7 @@ __global__ __launch_bounds__(256) void tune_select_kernel(const SongDesc* __rest
     };
     if (!songs[s].ok) { no_peaks(); return; }
     const uint32_t* hist = h1 + (size_t)s * H1_BINS;
-    constexpr int PER = H1_BINS / 256;  // 32 consecutive bins per thread
+    constexpr int PER = H1_BINS / 256;  // 64 consecutive bins per thread (64 VGPRs: no spill at 136)
     uint32_t local[PER], sum = 0;
 #pragma unroll
     for (int i = 0; i < PER; i++) { local[i] = hist[tid * PER + i]; sum += local[i]; }
@@ -1034,10 +1008,20 @@ __device__ __forceinline__ double interval_feature(const double (&c)[12]) {
     return acc;
 }
 
-#ifdef CHROMA_HANDPIPE
-// probe build only (tests/tools/variant.sh): the withdrawn hand-pipelined contraction of round 2 in place of chroma_kernel
-#include "../../tests/tools/probes/handpipe/chroma_handpipe.inc"
-#else
+__global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs, const uint32_t* __restrict__ pfx_cw,
+                              const uint32_t* __restrict__ pfx_ct, const float* __restrict__ spec,
+                              const double* __restrict__ bank, const TuningState* __restrict__ tuning,
+                              double* __restrict__ chroma_part);
+
+void launch_chroma(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
+    if (b.tiles_cw == 0) return;
+    hipLaunchKernelGGL(chroma_kernel, dim3(b.tiles_cw), dim3(256), 0, st, b.songs, b.n_songs, b.pfx_cw, b.pfx_ct, w.spec,
+                       t.chroma_bank, w.tuning, w.chroma_part);
+}
+
+// (a probe translation unit that brings its own contraction -- tests/tools/probes/handpipe -- defines this before it
+// includes this file)
+#ifndef BG_PROBE_REPLACES_CHROMA_KERNEL
 // One wavefront owns one 64-frame tile (= one chroma_part slot): four 16-frame MFMA sub-tiles share every
 // filter (A) fragment, so the L2-resident filter bank is read once per 64 frames instead of once per 16.
 __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs,
@@ -1085,9 +1069,11 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
     // A faster variant of this loop (v_mfma_f64_4x4x4_4b_f64: three instructions cover the 12 chroma rows exactly and run
     // at 77 instead of 61 TFLOP/s; spectrogram ring of three blocks and filter values staged through the LDS, all loads as
     // asm statements with hand-counted s_waitcnt vmcnt) ran at 6.0 ms, passed every parity test -- and returned a wrong
-    // chroma row about once in 5 000 songs of a multi-chunk batch (tests/tools/determinism_check.py; the same MFMAs with
-    // compiler-managed loads are clean but take 9.1 ms, because the compiler then drains the whole queue per block).  The
-    // cause was not found; the variant is not shipped.
+    // chroma row about once in 5 000 songs (tests/tools/determinism_check.py; the same MFMAs with compiler-managed loads
+    // are clean but take 9.1 ms, because the compiler then drains the whole queue per block).  Round 3 bisected it to the
+    // counted wait: `s_waitcnt vmcnt(8)` behind a mix of global->LDS transfers and ordinary loads fails, vmcnt(7) / (4) /
+    // (0) are clean (profiles/r03_handpipe_bisect.txt; probe build: tests/tools/probes/handpipe).  The variant is not
+    // shipped; nothing in the library mixes global->LDS transfers with counted waits.
     struct KBlock {
         double4_t a[2];
         float4 b[2][4];
@@ -1172,12 +1158,6 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
     }
 }
 
-#endif  // CHROMA_HANDPIPE
-
-void launch_chroma(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
-    if (b.tiles_cw == 0) return;
-    hipLaunchKernelGGL(chroma_kernel, dim3(b.tiles_cw), dim3(256), 0, st, b.songs, b.n_songs, b.pfx_cw, b.pfx_ct, w.spec,
-                       t.chroma_bank, w.tuning, w.chroma_part);
-}
+#endif  // BG_PROBE_REPLACES_CHROMA_KERNEL
 
 }  // namespace bg

@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
         OK(p_blissgpu_profile_get(c, k, &ms, &launches));
         if (launches) std::printf(" %s=%.3f", p_blissgpu_profile_kernel_name(k), ms / steps);
     }
-    if (auto p_trace = (int (*)(unsigned long long*, int))dlsym(h, "blissgpu_debug_stft_trace")) {  // -DSTFT_TRACE builds only
+    if (auto p_trace = (int (*)(unsigned long long*, int))dlsym(h, "blissgpu_debug_stft_trace")) {  // tests/tools/probes/stft_trace builds only
         unsigned long long tr[32];
         if (p_trace(tr, 1) == 0) {
             unsigned long long tot = 0;
@@ -109,7 +109,6 @@ int main(int argc, char** argv) {
     }
     std::vector<float> rows((size_t)n * 23);
     OK(p_blissgpu_memcpy_d2h(c, rows.data(), d_out, rows.size() * 4));
-    auto p_hp = (int (*)(unsigned long long*))dlsym(h, "blissgpu_debug_hp_mismatch");  // -DCHROMA_HANDPIPE -DHP_CHECK_A builds only
     if (const char* e = std::getenv("KBENCH_DETERMINISM")) {
         const int runs = std::atoi(e);
         OK(p_blissgpu_profile_enable(c, 0));
@@ -131,8 +130,6 @@ int main(int argc, char** argv) {
             bad_rows += b; bad_runs += b != 0;
         }
         std::printf("\n  determinism: %d runs x %u songs, %ld differing rows in %ld runs", runs, n, bad_rows, bad_runs);
-        unsigned long long hp[2];
-        if (p_hp && p_hp(hp) == 0) std::printf("\n  handpipe filter check: %llu values read from the LDS ring differ from the bank (%llu wavefronts ran)", hp[0], hp[1]);
     }
     uint64_t hash = 1469598103934665603ull;
     const unsigned char* b = (const unsigned char*)rows.data();
