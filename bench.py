@@ -207,6 +207,10 @@ def main_node(args):
         raise SystemExit("--node-devices must name --node ordinals")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the library has no CPU path")
+    if max(devices) >= torch.cuda.device_count():
+        raise SystemExit(f"--node-devices {devices}: only {torch.cuda.device_count()} HIP device(s) are visible")
+    if args.gpus not in (1, len(set(devices))):
+        raise SystemExit(f"--gpus {args.gpus} but --node drives {len(set(devices))} distinct device(s)")
     node = bliss.Node(world, devices=devices)
     loopback = len(set(devices)) < world
     N = args.samples
@@ -286,13 +290,31 @@ def main():
     import bliss_rs_amd as bliss
     from bliss_rs_amd.shard import all_gather_features, row_block, shard_songs
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the library has no CPU path")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > torch.cuda.device_count() and not args.share_device:
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible: refusing to "
+                         f"print a line for fewer GPUs than asked for")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launched as a plain process for N > 1 GPUs: become the launcher of N ranks (one per GPU over RCCL), exactly the
+        # command the module docstring gives; the ranks' single JSON line is this process's output
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} without WORLD_SIZE: launching {' '.join(cmd[1:9])} ...\n")
+        sys.stderr.flush()
+        raise SystemExit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the library has no CPU path")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: a line whose n_gpus is not --gpus is never printed")
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)

@@ -240,7 +240,7 @@ int blissgpu_ctx_destroy(blissgpu_ctx* c) {
         (void)hipFree(c->tw8192); (void)hipFree(c->tw512); (void)hipFree(c->hann8192); (void)hipFree(c->hannz512);
         (void)hipFree(c->bt_rwv); (void)hipFree(c->bt_dfwv); (void)hipFree(c->chroma_bank);
         scheduler_release(c);
-        c->dbg_tuning.release(); c->dbg_nbpms.release();
+        c->dbg_tuning.release(); c->dbg_nbpms.release(); c->dbg_chroma.release(); c->dbg_interval.release();
         c->pl_sync.release(); c->pl_keys.release(); c->pl_tmp.release(); c->pl_slots.release();
         c->st_a.release(); c->st_b.release(); c->st_m.release(); c->st_dist.release(); c->st_out.release();
         if (c->h_scalar) (void)hipHostFree(c->h_scalar);
@@ -288,6 +288,7 @@ int blissgpu_ctx_set_option(blissgpu_ctx* c, int option, int64_t value) {
         case BLISSGPU_OPT_TAIL_MODE: c->tail_mode = (int)value; break;
         case BLISSGPU_OPT_PIPELINE_CHUNKS: c->pipeline_chunks = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); break;
         case BLISSGPU_OPT_ROLLOFF_EXACT_ALL: c->rolloff_exact_all = value != 0; break;
+        case BLISSGPU_OPT_DEBUG_CHROMA: c->debug_chroma = value != 0; break;
         case BLISSGPU_OPT_CAND_BUDGET: c->cand_budget = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 714)); break;
         default: return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_set_option", "unknown option");
     }
@@ -742,6 +743,15 @@ int blissgpu_debug_last_tuning(blissgpu_ctx* c, double* tuning, uint32_t* n_bpms
 int blissgpu_debug_fetch(blissgpu_ctx* c, int what, uint32_t song, void* dst, uint64_t max_elems, uint64_t* n_elems) {
     if (!c || !dst) return fail(BLISSGPU_ERR_INVALID, "blissgpu_debug_fetch", "NULL argument");
     CTX_ENTER(c, "blissgpu_debug_fetch");
+    if (what == BLISSGPU_DEBUG_FILTER_BANK) {  // a table of the context, not of a batch: `song` is the tuning slot
+        if (song > (uint32_t)N_TUNING) return fail(BLISSGPU_ERR_INVALID, "blissgpu_debug_fetch", "tuning slot must be 0..100");
+        const uint64_t n = (uint64_t)BANK_ROWS * BANK_PITCH;
+        if (n_elems) *n_elems = n;
+        const uint64_t k = std::min(n, max_elems);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (k) HIP_TRY(hipMemcpy(dst, c->chroma_bank + (size_t)song * n, k * sizeof(double), hipMemcpyDeviceToHost));
+        return BLISSGPU_OK;
+    }
     // `song` is the caller's index into the last batch; the chunk keeps its songs in length order
     size_t pos = c->last_songs.size();
     for (size_t i = 0; i < c->last_songs.size(); i++)
@@ -765,6 +775,14 @@ int blissgpu_debug_fetch(blissgpu_ctx* c, int what, uint32_t song, void* dst, ui
         case BLISSGPU_DEBUG_ENERGY256: src = w.e256 + d.e_off; n = d.n_e; break;
         case BLISSGPU_DEBUG_CROSSINGS256: src = w.zc256 + d.e_off; n = d.n_e; break;
         case BLISSGPU_DEBUG_PITCH_HIST: src = w.hist100 + pos * N_TUNING; n = N_TUNING; break;
+        case BLISSGPU_DEBUG_CHROMA:
+        case BLISSGPU_DEBUG_INTERVAL:
+            if (!w.dbg_chroma || !w.dbg_interval)
+                return fail(BLISSGPU_ERR_INVALID, "blissgpu_debug_fetch", "set BLISSGPU_OPT_DEBUG_CHROMA before the analysis");
+            esz = 8;
+            if (what == BLISSGPU_DEBUG_CHROMA) { src = w.dbg_chroma + d.c_off * 12; n = (uint64_t)d.n_c * 12; }
+            else { src = w.dbg_interval + pos * 10; n = 10; }
+            break;
         default: return fail(BLISSGPU_ERR_INVALID, "blissgpu_debug_fetch", "unknown tap");
     }
     if (!d.ok) n = 0;

@@ -119,6 +119,7 @@ struct blissgpu_ctx {
                                        // per-song tails have a fixed latency per launch, so more chunks than memory needs lose)
     hipEvent_t ev_interop = nullptr;
     bool rolloff_exact_all = false;    // BLISSGPU_OPT_ROLLOFF_EXACT_ALL (tests)
+    bool debug_chroma = false;         // BLISSGPU_OPT_DEBUG_CHROMA (tests): keep the chroma matrix / interval means of the last chunk
     bool serial = false;               // BLISSGPU_OPT_SERIAL: single stream (clean per-kernel timings)
     uint64_t ws_limit = 0;             // bytes per chunk slot (set from the free device memory at creation)
     uint32_t cand_budget = bg::CAND_BUDGET_PER_FRAME;  // tuning-candidate pool: slots per chroma frame of a chunk
@@ -132,6 +133,7 @@ struct blissgpu_ctx {
     uint64_t chunk_seq = 0;            // chunks run so far
     bg::DevBuf<int32_t> dbg_tuning;
     bg::DevBuf<uint32_t> dbg_nbpms;
+    bg::DevBuf<double> dbg_chroma, dbg_interval;  // [chroma frames of the last chunk][12], [its songs][10] (BLISSGPU_OPT_DEBUG_CHROMA)
     uint32_t dbg_n = 0;
     bg::Workspace last_ws{};                 // workspace carving of the last chunk (debug taps)
     std::vector<bg::SongDesc> last_songs;    // its descriptors (chunk order; SongDesc::row = the caller's song index)

@@ -148,6 +148,8 @@ struct Workspace {
     uint32_t* cand_cursor;  // [0] next free pool slot
     uint32_t cand_cap;
     double* chroma_part;    // [total chroma tiles][10] partial sums of interval features
+    double* dbg_chroma;     // [total_c][12] chroma_stft's normalised columns, or NULL (BLISSGPU_OPT_DEBUG_CHROMA)
+    double* dbg_interval;   // [n_songs][10] interval means before the normalisation, or NULL
     TempoState* tempo;      // [n_songs]
     float* run_bpm;         // [n_songs][runs_pitch] bpm after each beat-tracker run
     uint32_t* run_cnt;      // [n_songs][runs_pitch] beats recorded while that bpm was current

@@ -1011,12 +1011,12 @@ __device__ __forceinline__ double interval_feature(const double (&c)[12]) {
 __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs, const uint32_t* __restrict__ pfx_cw,
                               const uint32_t* __restrict__ pfx_ct, const float* __restrict__ spec,
                               const double* __restrict__ bank, const TuningState* __restrict__ tuning,
-                              double* __restrict__ chroma_part);
+                              double* __restrict__ chroma_part, double* __restrict__ dbg_chroma);
 
 void launch_chroma(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.tiles_cw == 0) return;
     hipLaunchKernelGGL(chroma_kernel, dim3(b.tiles_cw), dim3(256), 0, st, b.songs, b.n_songs, b.pfx_cw, b.pfx_ct, w.spec,
-                       t.chroma_bank, w.tuning, w.chroma_part);
+                       t.chroma_bank, w.tuning, w.chroma_part, w.dbg_chroma);
 }
 
 // (a probe translation unit that brings its own contraction -- tests/tools/probes/handpipe -- defines this before it
@@ -1030,7 +1030,8 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
                                                      const float* __restrict__ spec,
                                                      const double* __restrict__ bank,
                                                      const TuningState* __restrict__ tuning,
-                                                     double* __restrict__ chroma_part) {
+                                                     double* __restrict__ chroma_part,
+                                                     double* __restrict__ dbg_chroma) {
     __shared__ double tile_c[4][4][16][13];
     const uint32_t s = find_segment(pfx_cw, n_songs, blockIdx.x);
     const SongDesc sd = songs[s];
@@ -1132,6 +1133,10 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
 #pragma unroll
         for (int k = 0; k < 12; k++) { c[k] = tile_c[wave][lane >> 4][lane & 15][k]; sum += fabs(c[k]); }
         if (sum < DBL_MIN) sum = 1.0;          // chroma_stft column normalisation (:404-410)
+        if (dbg_chroma) {  // wave-uniform (tap of the parity tests): chroma_stft's column of this frame
+#pragma unroll
+            for (int k = 0; k < 12; k++) dbg_chroma[(sd.c_off + f0 + lane) * 12 + k] = c[k] / sum;
+        }
         double esum = 0.0;
 #pragma unroll
         for (int k = 0; k < 12; k++) { c[k] = exp((c[k] / sum) * 15.0); esum += fabs(c[k]); }

@@ -146,7 +146,8 @@ __global__ __launch_bounds__(64) void assemble_kernel(const SongDesc* __restrict
                                                       uint32_t features_version, float* __restrict__ out,
                                                       int32_t* __restrict__ status,
                                                       int32_t* __restrict__ dbg_tuning,
-                                                      uint32_t* __restrict__ dbg_nbpms) {
+                                                      uint32_t* __restrict__ dbg_nbpms,
+                                                      double* __restrict__ dbg_interval) {
     const uint32_t s = blockIdx.x * 64 + threadIdx.x;
     if (s >= n_songs) return;
     const SongDesc sd = songs[s];
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(const SongDesc* __restrict
         double acc = 0.0;
         for (uint32_t k = t0; k < t1; k++) acc += chroma_part[(size_t)k * 10 + t];
         raw[t] = acc / (double)sd.n_c;
+        if (dbg_interval) dbg_interval[(size_t)s * 10 + t] = raw[t];  // tap of the parity tests
     }
     if (features_version == 1) {
         for (int t = 0; t < 10; t++) feat[10 + t] = 2.0f * ((float)raw[t] - 0.0f) / (0.12f - 0.0f) - 1.0f;
@@ -280,7 +282,8 @@ void launch_finalize(const Batch& b, const Workspace& w, uint32_t features_versi
                      int32_t* dbg_tuning, uint32_t* dbg_nbpms, hipStream_t st) {
     if (b.n_songs == 0) return;
     hipLaunchKernelGGL(assemble_kernel, dim3((b.n_songs + 63) / 64), dim3(64), 0, st, b.songs, b.n_songs, b.pfx_ct,
-                       w.summary, w.chroma_part, w.tempo, w.tuning, features_version, d_out, d_status, dbg_tuning, dbg_nbpms);
+                       w.summary, w.chroma_part, w.tempo, w.tuning, features_version, d_out, d_status, dbg_tuning, dbg_nbpms,
+                       w.dbg_interval);
 }
 
 }  // namespace bg

@@ -190,6 +190,14 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
 
     size_t used_bytes = 0;
     slot.ws = carve(slot.slab.p, ns, t, &used_bytes);
+    slot.ws.dbg_chroma = nullptr;
+    slot.ws.dbg_interval = nullptr;
+    if (c->debug_chroma) {  // taps of the parity tests: the buffers belong to the context, the last chunk's contents stay
+        if ((rc = c->dbg_chroma.ensure((size_t)t.tot_c * 12 + 12))) return rc;
+        if ((rc = c->dbg_interval.ensure((size_t)ns * 10))) return rc;
+        slot.ws.dbg_chroma = c->dbg_chroma.p;
+        slot.ws.dbg_interval = c->dbg_interval.p;
+    }
     const Workspace& w = slot.ws;
     c->last_ws = w;
     c->last_songs.assign(songs, songs + ns);

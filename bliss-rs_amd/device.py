@@ -59,7 +59,8 @@ class Context:
         _ffi.check(self._L.blissgpu_ctx_synchronize(self._h))
 
     OPTIONS = {"serial": _ffi.OPT_SERIAL, "tail_mode": _ffi.OPT_TAIL_MODE, "pipeline_chunks": _ffi.OPT_PIPELINE_CHUNKS,
-               "cand_budget": _ffi.OPT_CAND_BUDGET, "rolloff_exact_all": _ffi.OPT_ROLLOFF_EXACT_ALL}
+               "cand_budget": _ffi.OPT_CAND_BUDGET, "rolloff_exact_all": _ffi.OPT_ROLLOFF_EXACT_ALL,
+               "debug_chroma": _ffi.OPT_DEBUG_CHROMA}
 
     def set_option(self, name: str, value: int):
         """Scheduling knobs for the measurement tools and the tests (blissgpu_ctx_set_option)."""
@@ -122,10 +123,24 @@ class Context:
     TAPS = {"centroid": (0, np.float32), "rolloff": (1, np.float32), "flatness": (2, np.float32),
             "flux": (3, np.float32), "thresholded": (4, np.float32), "run_bpm": (5, np.float32),
             "run_count": (6, np.uint32), "spectrogram": (7, np.float32), "energy256": (8, np.float32),
-            "crossings256": (9, np.uint32), "pitch_hist": (10, np.uint32)}
+            "crossings256": (9, np.uint32), "pitch_hist": (10, np.uint32),
+            # f64 taps; "chroma" / "interval" need set_option("debug_chroma", 1) before the analysis; for "filter_bank" the
+            # `song` argument is the tuning slot (0..99: tuning -0.5 + 0.01 slot, 100: tuning 0.0)
+            "chroma": (11, np.float64), "interval": (12, np.float64), "filter_bank": (13, np.float64)}
 
     def debug_fetch(self, what: str, song: int) -> np.ndarray:
         """Intermediate series of one song of the last chunk (per-stage parity tests)."""
+        out = self.debug_fetch_raw(what, song)
+        if what == "spectrogram":
+            out = out.reshape(-1, 4128)[:, :4097]
+        elif what == "filter_bank":
+            out = out.reshape(12, 4128)[:, :4097]
+        elif what == "chroma":
+            out = out.reshape(-1, 12)
+        return out
+
+    def debug_fetch_raw(self, what: str, song: int) -> np.ndarray:
+        """The tap as the device holds it (flat, padding included)."""
         code, dt = self.TAPS[what]
         n = C.c_uint64()
         probe = np.empty(1, dt)
@@ -133,8 +148,6 @@ class Context:
         out = np.empty(n.value, dt)
         if n.value:
             _ffi.check(self._L.blissgpu_debug_fetch(self._h, code, song, C.c_void_p(out.ctypes.data), n.value, C.byref(n)))
-        if what == "spectrogram":
-            out = out.reshape(-1, 4128)[:, :4097]
         return out
 
     # ---- distances ----

@@ -90,6 +90,8 @@ int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
 #define BLISSGPU_OPT_CAND_BUDGET 3      /* tuning-candidate pool: slots per chroma frame (default 48; 0 starves the pool) */
 #define BLISSGPU_OPT_ROLLOFF_EXACT_ALL 4 /* 1: every frame's rolloff bin through the reference-order pass, not only the frames
                                            the FFT-512 kernel cannot prove (tests: both must give the same rows) */
+#define BLISSGPU_OPT_DEBUG_CHROMA 5     /* 1: the contraction also keeps chroma_stft's matrix and the assembly the interval
+                                           means of the last chunk for the CHROMA / INTERVAL taps below (96 B per frame) */
 int blissgpu_ctx_set_option(blissgpu_ctx *ctx, int option, int64_t value);
 
 /* The default contexts: how many there are, the HIP ordinal of the k-th, and how many coalesced batches of single-song
@@ -270,8 +272,8 @@ int blissgpu_debug_last_tuning(blissgpu_ctx *ctx, double *tuning, uint32_t *n_bp
 uint64_t blissgpu_debug_last_chunks(blissgpu_ctx *ctx);
 
 /* Intermediate series of song `song` (the caller's index into the last batch; it must belong to the LAST chunk run
- * on ctx) for the per-stage parity tests.  Copies at most max_elems 4-byte elements to dst, reports the available
- * count in *n_elems. */
+ * on ctx) for the per-stage parity tests.  Copies at most max_elems elements (4 bytes; 8 for the f64 taps) to dst,
+ * reports the available count in *n_elems. */
 #define BLISSGPU_DEBUG_CENTROID 0      /* f32[n_t]  per-frame spectral centroid in Hz (src/timbral.rs:159-173) */
 #define BLISSGPU_DEBUG_ROLLOFF 1       /* f32[n_t]  per-frame rolloff in Hz (:175-194) */
 #define BLISSGPU_DEBUG_FLATNESS 2      /* f32[n_t]  per-frame flatness (:196-208) */
@@ -283,6 +285,12 @@ uint64_t blissgpu_debug_last_chunks(blissgpu_ctx *ctx);
 #define BLISSGPU_DEBUG_ENERGY256 8     /* f32[ceil(n/256)] sum of squares per 256 samples */
 #define BLISSGPU_DEBUG_CROSSINGS256 9  /* u32[ceil(n/256)] zero crossings per 256 samples */
 #define BLISSGPU_DEBUG_PITCH_HIST 10   /* u32[100] pitch-residue histogram (peaks above the median's coarse bin) */
+/* f64 taps (elements are 8 bytes).  CHROMA and INTERVAL need BLISSGPU_OPT_DEBUG_CHROMA = 1 before the analysis. */
+#define BLISSGPU_DEBUG_CHROMA 11       /* f64[n_c][12] chroma_stft's matrix, frame-major, after the column normalisation
+                                          (src/chroma.rs:393-412; the reference holds it against data/chroma.npy, :621-639) */
+#define BLISSGPU_DEBUG_INTERVAL 12     /* f64[10] chroma_interval_features' time means (src/chroma.rs:137-155) */
+#define BLISSGPU_DEBUG_FILTER_BANK 13  /* f64[12][4128] chroma_filter(22050, 8192, 12, tuning) (src/chroma.rs:197-267), 4097
+                                          valid per row; `song` is the TUNING SLOT: 0..99 = tuning -0.5 + 0.01 slot, 100 = 0.0 */
 int blissgpu_debug_fetch(blissgpu_ctx *ctx, int what, uint32_t song, void *dst, uint64_t max_elems, uint64_t *n_elems);
 
 const char *blissgpu_strerror(int code);
