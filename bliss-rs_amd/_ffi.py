@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BLISSGPU_LIB: developer aid for A/B timing of two builds of the library on the same box (never a CPU path)
 LIB_PATH = os.environ.get("BLISSGPU_LIB") or os.path.join(_HERE, "libblissgpu.so")
 
-OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_NAN, ERR_RCCL = 0, 1, 2, 3, 4, 5, 6
+OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_NAN, ERR_RCCL, ERR_TIMEOUT = 0, 1, 2, 3, 4, 5, 6, 7
 SAMPLE_F32, SAMPLE_S16 = 0, 1
 SONG_OK, SONG_TOO_SHORT = 0, 1
 METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_MAHALANOBIS = 0, 1, 2
@@ -39,6 +39,7 @@ SIGNATURES = {
     "blissgpu_default_device_count": (C.c_int, []),
     "blissgpu_default_device": (C.c_int, [C.c_int]),
     "blissgpu_default_device_batches": (C.c_uint64, [C.c_int]),
+    "blissgpu_set_single_song_timeout_ms": (C.c_int, [C.c_int64]),
     "blissgpu_feature_count": (C.c_uint32, [C.c_uint32]),
     "blissgpu_analyze": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _i32p]),
     "blissgpu_analyze_interleaved": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, _vp, _i32p]),

@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -88,9 +90,20 @@ int build_tables(blissgpu_ctx* c) {
 // one-GPU box).
 std::mutex g_default_mu;
 std::vector<int> g_default_devices;
-std::vector<blissgpu_ctx*> g_default_ctxs;
+// A default context is created under ITS OWN mutex (building the 40 MB filter bank takes a while: the seats of an 8-GPU node
+// must not queue behind one another, and the counters below must stay readable meanwhile); a creation that failed is
+// remembered -- the seat is retired by the front -- and not retried on every call.
+struct DefaultSeat {
+    std::mutex mu;
+    blissgpu_ctx* ctx = nullptr;
+    bool tried = false;
+    int rc = BLISSGPU_OK;
+    std::string err;
+};
+std::deque<DefaultSeat> g_default_seats;  // (stable addresses)
 std::vector<uint64_t> g_default_batches;
 bool g_default_init = false;
+std::atomic<int64_t> g_single_song_timeout_ms{600000};
 
 void default_init_locked() {
     if (g_default_init) return;
@@ -110,7 +123,7 @@ void default_init_locked() {
         if (hipGetDeviceCount(&count) != hipSuccess || count < 1) count = 1;  // no device: ctx_create reports it
         for (int k = 0; k < count && k < 64; k++) g_default_devices.push_back(k);
     }
-    g_default_ctxs.assign(g_default_devices.size(), nullptr);
+    g_default_seats.resize(g_default_devices.size());
     g_default_batches.assign(g_default_devices.size(), 0);
 }
 
@@ -123,16 +136,29 @@ int default_ctx_count() {
     return (int)g_default_devices.size();
 }
 int default_ctx_at(int k, blissgpu_ctx** out) {
-    std::lock_guard<std::mutex> lk(g_default_mu);
-    default_init_locked();
-    if (k < 0 || k >= (int)g_default_devices.size()) return fail(BLISSGPU_ERR_INVALID, "default context", "no such default device");
-    if (!g_default_ctxs[k]) {
-        int rc = blissgpu_ctx_create(g_default_devices[k], &g_default_ctxs[k]);
-        if (rc) return rc;
+    DefaultSeat* seat = nullptr;
+    int device = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_default_mu);
+        default_init_locked();
+        if (k < 0 || k >= (int)g_default_devices.size()) return fail(BLISSGPU_ERR_INVALID, "default context", "no such default device");
+        seat = &g_default_seats[(size_t)k];
+        device = g_default_devices[(size_t)k];
     }
-    *out = g_default_ctxs[k];
+    std::lock_guard<std::mutex> lk(seat->mu);
+    if (!seat->tried) {
+        seat->tried = true;
+        seat->rc = blissgpu_ctx_create(device, &seat->ctx);
+        if (seat->rc) {
+            seat->ctx = nullptr;
+            seat->err = std::string("default context ") + std::to_string(k) + " (HIP device " + std::to_string(device) + "): " + blissgpu_last_error();
+        }
+    }
+    if (seat->rc) return fail(seat->rc, "default context", seat->err.c_str());
+    *out = seat->ctx;
     return BLISSGPU_OK;
 }
+int64_t single_song_timeout_ms() { return g_single_song_timeout_ms.load(); }
 int default_ctx(blissgpu_ctx** out) { return default_ctx_at(0, out); }
 void default_ctx_count_batch(int k) {
     std::lock_guard<std::mutex> lk(g_default_mu);
@@ -142,6 +168,10 @@ void default_ctx_count_batch(int k) {
 
 extern "C" {
 int blissgpu_default_device_count(void) { return default_ctx_count(); }
+int blissgpu_set_single_song_timeout_ms(int64_t ms) {
+    g_single_song_timeout_ms.store(ms > 0 ? ms : 600000);
+    return BLISSGPU_OK;
+}
 int blissgpu_default_device(int k) {
     std::lock_guard<std::mutex> lk(g_default_mu);
     default_init_locked();
@@ -184,6 +214,7 @@ const char* blissgpu_strerror(int code) {
         case BLISSGPU_ERR_NAN: return "a distance is NaN";
         case BLISSGPU_ERR_OOM: return "out of device memory";
         case BLISSGPU_ERR_RCCL: return "RCCL error";
+        case BLISSGPU_ERR_TIMEOUT: return "no default context picked the call up within its deadline";
         default: return "unknown error";
     }
 }

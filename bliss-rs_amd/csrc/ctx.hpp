@@ -185,6 +185,7 @@ int default_ctx_count();
 int default_ctx_at(int k, blissgpu_ctx** out);
 int default_ctx(blissgpu_ctx** out);  // = default_ctx_at(0): the batch / distance / playlist forms without a context argument
 void default_ctx_count_batch(int k);  // statistics: one more coalesced batch served by default context k
+int64_t single_song_timeout_ms();     // blissgpu_set_single_song_timeout_ms
 
 // scheduler.hip
 void scheduler_release(blissgpu_ctx* c);

@@ -440,15 +440,35 @@ struct AnalyzeReq {
     int rc = BLISSGPU_OK;
     std::string err;
     bool done = false;
+    int front_outcome = 0;  // bg::FrontOutcome
 };
+
+// the calling thread's current HIP device is the caller's business: a leader works on its seat's device and puts the
+// caller's device back (a caller's later hipMalloc / torch allocation must not land on whatever GPU served the batch)
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+    ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+std::mutex g_seat_err_mu;
+std::string g_seat_err;  // why the last seat was retired (reported when no seat is left)
 
 // The queue, the seats and the waiting are in coalescing_front.hpp (device-free: tests/cpp/test_front.cpp drives it on the
 // CPU); a leader's batch runs on the default context of its seat.
 bg::CoalescingFront<AnalyzeReq> g_front;
 
-void run_batch(std::vector<AnalyzeReq*>& take, int seat, const char* who) {
+// true: the batch was dealt with (every request carries its result); false: the seat's device cannot give a context --
+// nothing was done, the front retires the seat and hands the batch to another one
+bool run_batch(std::vector<AnalyzeReq*>& take, int seat, const char* who) {
+    DeviceRestore restore;
     blissgpu_ctx* c = nullptr;
     const int rc0 = default_ctx_at(seat, &c);
+    if (rc0) {
+        std::lock_guard<std::mutex> lk(g_seat_err_mu);
+        g_seat_err = blissgpu_last_error();
+        return false;
+    }
     // one device batch per (sample format, channels, features version) class; in practice there is one class
     std::vector<char> served(take.size(), 0);
     for (size_t a = 0; a < take.size(); a++) {
@@ -466,9 +486,8 @@ void run_batch(std::vector<AnalyzeReq*>& take, int seat, const char* who) {
         std::vector<int32_t> st(cls.size(), 0);
         std::vector<float> rows(cls.size() * (size_t)std::max(d, 1u));
         for (size_t q = 0; q < cls.size(); q++) { ptrs[q] = take[cls[q]]->pcm; lens[q] = take[cls[q]]->frames; }
-        const int rc = rc0 ? rc0
-                           : analyze_host_songs(c, ptrs.data(), lens.data(), (uint32_t)cls.size(), take[a]->bytes_per_sample,
-                                                take[a]->channels, take[a]->version, rows.data(), st.data(), who);
+        const int rc = analyze_host_songs(c, ptrs.data(), lens.data(), (uint32_t)cls.size(), take[a]->bytes_per_sample,
+                                          take[a]->channels, take[a]->version, rows.data(), st.data(), who);
         const std::string err = rc ? blissgpu_last_error() : "";
         for (size_t q = 0; q < cls.size(); q++) {
             AnalyzeReq* t = take[cls[q]];
@@ -479,17 +498,30 @@ void run_batch(std::vector<AnalyzeReq*>& take, int seat, const char* who) {
         }
     }
     default_ctx_count_batch(seat);
+    return true;
 }
 
 int submit(AnalyzeReq& r, const char* who) {
-    g_front.submit(r, default_ctx_count(), [&](std::vector<AnalyzeReq*>& take, int seat) {
-        // a failed allocation while gathering the batch becomes an error code on every request of the batch
-        try {
-            run_batch(take, seat, who);
-        } catch (...) {
-            for (AnalyzeReq* t : take) { t->rc = BLISSGPU_ERR_OOM; t->err = "out of host memory while gathering the batch"; }
-        }
-    });
+    const bg::FrontOutcome o = g_front.submit(
+        r, default_ctx_count(),
+        [&](std::vector<AnalyzeReq*>& take, int seat) -> bool {
+            // a failed allocation while gathering the batch becomes an error code on every request of the batch
+            try {
+                return run_batch(take, seat, who);
+            } catch (...) {
+                for (AnalyzeReq* t : take) { t->rc = BLISSGPU_ERR_OOM; t->err = "out of host memory while gathering the batch"; }
+                return true;
+            }
+        },
+        std::chrono::milliseconds(single_song_timeout_ms()));
+    if (o == bg::FRONT_NO_SEAT) {
+        std::string why;
+        { std::lock_guard<std::mutex> lk(g_seat_err_mu); why = g_seat_err; }
+        return fail(BLISSGPU_ERR_NO_DEVICE, who, ("no usable default context (" + g_front.describe() + "); last failure: " + why).c_str());
+    }
+    if (o == bg::FRONT_TIMED_OUT)
+        return fail(BLISSGPU_ERR_TIMEOUT, who,
+                    ("not picked up by a default context within " + std::to_string(single_song_timeout_ms()) + " ms: " + g_front.describe()).c_str());
     if (r.rc) return fail(r.rc, who, r.err.c_str());
     return BLISSGPU_OK;
 }
@@ -510,6 +542,7 @@ int batch_from_offsets(const void* pcm, size_t frame_bytes, const uint64_t* offs
     if (n_songs && (!pcm || !offsets || !lengths || !out)) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
     if (!blissgpu_feature_count(version)) return fail(BLISSGPU_ERR_INVALID, who, "features_version must be 1 or 2");
     if (n_songs == 0) return BLISSGPU_OK;
+    DeviceRestore restore;
     blissgpu_ctx* c;
     int rc = default_ctx(&c);
     if (rc) return rc;

@@ -41,6 +41,8 @@ extern "C" {
 #define BLISSGPU_ERR_OOM 4            /* workspace allocation failed */
 #define BLISSGPU_ERR_NAN 5            /* a distance is NaN: the reference panics there (n32(), argmin().unwrap()) */
 #define BLISSGPU_ERR_RCCL 6           /* librccl could not be loaded or a collective failed (blissgpu_node_* only) */
+#define BLISSGPU_ERR_TIMEOUT 7        /* a single-song call was not picked up by any default context within its deadline
+                                         (blissgpu_set_single_song_timeout_ms); blissgpu_last_error() names the seats */
 
 /* ---- per-song status, maps 1:1 onto BlissError (src/lib.rs:236-252) ---- */
 #define BLISSGPU_SONG_OK 0
@@ -99,6 +101,11 @@ int blissgpu_ctx_set_option(blissgpu_ctx *ctx, int option, int64_t value);
 int blissgpu_default_device_count(void);
 int blissgpu_default_device(int k);
 uint64_t blissgpu_default_device_batches(int k);
+/* How long a single-song call (blissgpu_analyze / _interleaved) may wait for a default context to pick it up before it
+ * fails with BLISSGPU_ERR_TIMEOUT instead of blocking (default 600 000 ms; <= 0 restores the default).  A default context
+ * whose device cannot give a context is retired -- its traffic goes to the others -- and only when all are retired do the
+ * calls fail, with the creation error. */
+int blissgpu_set_single_song_timeout_ms(int64_t ms);
 
 uint32_t blissgpu_feature_count(uint32_t features_version); /* FeaturesVersion::feature_count, src/lib.rs:181-186 */
 

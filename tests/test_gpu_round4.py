@@ -313,3 +313,49 @@ def test_threads_over_real_default_contexts(tmp_path):
     assert int(kv["default_devices"]) == world
     served = [int(kv[f"default_device_{k}_batches"]) for k in range(world)]
     assert all(v > 0 for v in served), served
+
+
+# ---------------------------------------------------------------------------------------------
+# a default context whose device cannot give a context is retired; the others take its traffic
+# ---------------------------------------------------------------------------------------------
+def test_front_retires_a_seat_whose_device_is_missing(tmp_path):
+    """BLISSGPU_DEFAULT_DEVICES=0,99: the second default context cannot be created (no HIP device 99).  16 threads x 32
+    single-song calls must all succeed, bit-identical to the serial run, through seat 0 alone -- before round 4 every batch
+    that drew the broken seat failed, and that seat, free again at once, kept drawing traffic."""
+    import subprocess
+
+    from test_gpu_round3 import _kv, _threads_exe
+
+    exe = _threads_exe(tmp_path)
+    out = subprocess.run([str(exe), "16", "32"], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, BLISSGPU_DEFAULT_DEVICES="0,99"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all checks passed" in out.stdout
+    kv = _kv(out.stdout)
+    assert kv["default_devices"] == "2" and kv["default_device_1_hip_ordinal"] == "99"
+    assert int(kv["default_device_0_batches"]) > 0 and int(kv["default_device_1_batches"]) == 0, out.stdout
+
+
+def test_front_fails_loudly_when_no_seat_is_usable():
+    """every default device is missing: the call fails with BLISSGPU_ERR_NO_DEVICE, says which seats were retired and why,
+    and a second call fails the same way at once (nothing blocks, nothing is retried for ever)"""
+    import subprocess
+
+    code = (
+        "import ctypes as C, numpy as np, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "from bliss_rs_amd import _ffi\n"
+        "L = _ffi.lib()\n"
+        "x = np.zeros(30000, np.float32); out = np.zeros(23, np.float32); st = C.c_int32(0)\n"
+        "for k in range(2):\n"
+        "    t = time.time()\n"
+        "    rc = L.blissgpu_analyze(x.ctypes.data_as(C.POINTER(C.c_float)), len(x), 2, out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st))\n"
+        "    print(rc, round(time.time() - t, 1) < 30, L.blissgpu_last_error().decode())\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, BLISSGPU_DEFAULT_DEVICES="98,99"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 2
+    for ln in lines:
+        assert ln.startswith("1 True "), ln                       # BLISSGPU_ERR_NO_DEVICE, promptly
+        assert "retired, retired" in ln and "HIP device 9" in ln, ln

@@ -293,14 +293,36 @@ print(n, [L.blissgpu_default_device(k) for k in range(n)], L.blissgpu_default_de
 @pytest.mark.parametrize("seats", [1, 2, 8])
 def test_coalescing_front_on_the_cpu(tmp_path, seats):
     """The group-commit front of the single-song entry points (bliss-rs_amd/csrc/coalescing_front.hpp) is device-free:
-    32 threads x 1500 calls against 1 / 2 / 8 seats with a batch runner that sleeps.  Every request runs exactly once, no
-    seat runs two batches at a time, several seats are used -- and the run ends: with more than one seat the first form of
-    this loop could spin with the mutex held when another leader had taken a caller's request along (a hung -m gpu run)."""
+    32 threads x 1500 calls against 1 / 2 / 8 seats with a batch runner that sleeps for a RANDOM time and now and then
+    throws in the middle of its batch.  Every request runs exactly once, no seat runs two batches at a time, several seats
+    are used -- and the run ends: with more than one seat the first form of this loop could spin with the mutex held when
+    another leader had taken a caller's request along (a hung -m gpu run)."""
     exe = tmp_path / "test_front"
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_front.cpp"), "-o", str(exe)])
     out = subprocess.run([str(exe), "32", "1500", str(seats), "300"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "bad 0" in out.stdout and f"of {seats}" in out.stdout
+
+
+TSAN_CXX = "/opt/rocm/lib/llvm/bin/clang++"   # (g++ 11's libtsan does not know pthread_cond_clockwait: false reports on wait_for)
+
+
+@pytest.mark.skipif(not os.path.exists(TSAN_CXX), reason="needs the ROCm clang for -fsanitize=thread")
+def test_coalescing_front_under_thread_sanitizer(tmp_path):
+    """The same test built with -fsanitize=thread, through every scenario of tests/cpp/test_front.cpp: plain (random batch
+    durations, leaders that fail mid-batch), one seat whose device cannot give a context (retired after ONE attempt, all
+    its traffic served elsewhere), every seat unusable (every call refused, none blocks), and leaders that hang while the
+    queued callers come back by themselves at their deadline.  No data race, no lock-order report, exit code 0."""
+    exe = tmp_path / "test_front_tsan"
+    subprocess.check_call([TSAN_CXX, "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=thread",
+                           os.path.join(ROOT, "tests", "cpp", "test_front.cpp"), "-o", str(exe)])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    for args in (["32", "300", "1", "300", "0"], ["32", "300", "4", "300", "0"], ["32", "300", "8", "300", "0"],
+                 ["32", "200", "4", "300", "1"], ["16", "50", "4", "300", "2"], ["16", "60", "3", "300", "3"]):
+        out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, (args, out.stdout[-1500:], out.stderr[-3000:])
+        assert "ThreadSanitizer" not in out.stderr, (args, out.stderr[-3000:])
+        assert "bad 0" in out.stdout
 
 
 def test_rolloff_guard_on_emulated_summation_orders():
