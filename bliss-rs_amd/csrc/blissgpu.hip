@@ -551,7 +551,6 @@ int blissgpu_song_to_song_device(blissgpu_ctx* c, const float* d_seeds, uint32_t
     // four candidates per thread (register-resident) is the sweet spot: fewer workgroups make the grid barrier and the
     // slot reduction cheaper (100 k songs: 98 workgroups, 7.3 us per step; 256 workgroups with two each: 11.7 us)
     uint32_t grid = (uint32_t)std::min<uint64_t>((n + 1023) / 1024, (uint64_t)std::min(256, std::max(1, c->n_cus)));
-    if (const char* e = getenv("BLISSGPU_S2S_GRID")) grid = std::min<uint32_t>(256u, (uint32_t)std::max(1, atoi(e)));  // experiment
     if ((n + (uint64_t)grid * 256 - 1) / ((uint64_t)grid * 256) > 64)
         return fail(BLISSGPU_ERR_INVALID, "blissgpu_song_to_song_device", "pool too large for one launch (> 64 candidates per thread)");
     rc = c->pl_sync.ensure(4);

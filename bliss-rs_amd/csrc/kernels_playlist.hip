@@ -13,8 +13,6 @@
 // local scan -> workgroup min -> one 8-byte slot per workgroup -> grid barrier -> every workgroup reduces the
 // G slots redundantly.  Keys are (order-preserving u32 image of the distance) << 32 | candidate index, so the
 // u64 minimum is the first minimum in pool order (Vec::remove keeps the relative order of the pool).
-#include <hipcub/hipcub.hpp>
-
 #include "device_utils.hpp"
 #include "internal.hpp"
 
@@ -104,11 +102,129 @@ void launch_set_distance(const float* seeds, uint32_t n_seeds, const float* cand
                        d, metric, M, dist, keys, idx, nan_flag);
 }
 
-// stable LSD radix sort of (key, index) pairs: equal distances keep their original order, like
-// slice::sort_by_cached_key
-hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                          const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, hipStream_t st) {
-    return hipcub::DeviceRadixSort::SortPairs(tmp, *tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 32, st);
+// ---- stable LSD radix sort of (key, index) pairs: equal distances keep their original order, like
+// slice::sort_by_cached_key (src/playlist.rs:256-270).  Four passes of eight bits; per pass
+//   radix_hist_kernel     a workgroup counts the digits of its tile of 2048 pairs (LDS histogram)     -> hist[digit][tile]
+//   radix_scan_kernel     one workgroup turns the digit-major table into exclusive offsets (a stable sort places digit d
+//                         of tile b behind every smaller digit and behind digit d of the tiles before b)
+//   radix_scatter_kernel  a wavefront owns 512 consecutive pairs of the tile, eight at a time in order: the lanes that hold
+//                         the same digit find one another with eight ballots (one per digit bit), a lane's rank among them
+//                         is the population count of the match mask below it, the wavefront's running count per digit
+//                         lives in LDS; the four wavefronts' counts are stacked in tile order and added to the tile's
+//                         offset.  No pair ever overtakes an equal one.
+// The pairs ping-pong in -> tmp -> in -> tmp -> out.  100 000 pairs: twelve launches of a few microseconds.
+constexpr int RS_ITEMS = 8, RS_TILE = 256 * RS_ITEMS;
+
+__global__ __launch_bounds__(256) void radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                         uint32_t* __restrict__ hist, uint32_t n_tiles) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (uint32_t)RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        const uint32_t j = base + (uint32_t)i * 256u + threadIdx.x;
+        if (j < n) atomicAdd(&h[(keys[j] >> shift) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of `len` counters in place, one workgroup (len = 256 x tiles: 12 544 for 100 000 pairs)
+__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ v, uint32_t len) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t per = (len + 255u) / 256u;            // consecutive counters per thread
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < len ? lo + per : len;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += v[i];
+    const uint32_t incl = wave_scan_incl_u32(sum);
+    if (lane_id() == 63) wsum[wave_id()] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave_id(); w++) run += wsum[w];
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t c = v[i];
+        v[i] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                            uint32_t n, int shift, const uint32_t* __restrict__ offs,
+                                                            uint32_t n_tiles) {
+    __shared__ uint32_t wcount[4][256];   // pairs with digit d the wavefront has placed so far; later: its first output slot
+    const int lane = lane_id(), wave = wave_id();
+    for (int i = threadIdx.x; i < 4 * 256; i += 256) (&wcount[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (uint32_t)RS_TILE + (uint32_t)wave * (64u * RS_ITEMS);
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        const uint32_t j = base + 64u * i + (uint32_t)lane;
+        key[i] = j < n ? keys_in[j] : 0xFFFFFFFFu;
+        val[i] = j < n ? vals_in[j] : 0u;
+    }
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        const bool live = base + 64u * i + (uint32_t)lane < n;
+        const uint32_t dgt = (key[i] >> shift) & 0xFFu;
+        uint64_t match = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t has = __ballot((dgt >> b) & 1u);
+            match &= ((dgt >> b) & 1u) ? has : ~has;
+        }
+        // every lane of a match group reads the group's count so far, then its first lane adds the group (a wavefront's
+        // LDS accesses execute in program order)
+        const uint32_t before = live ? wcount[wave][dgt] : 0u;
+        rank[i] = before + (uint32_t)__popcll(match & below);
+        if (live && (match & below) == 0) wcount[wave][dgt] = before + (uint32_t)__popcll(match);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+        // thread d: where the tile's digit d starts, and where each wavefront's share of it starts (tile order)
+        const uint32_t d = threadIdx.x;
+        uint32_t run = offs[(size_t)d * n_tiles + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t c = wcount[w][d];
+            wcount[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        if (base + 64u * i + (uint32_t)lane < n) {
+            const uint32_t dst = wcount[wave][(key[i] >> shift) & 0xFFu] + rank[i];
+            keys_out[dst] = key[i];
+            vals_out[dst] = val[i];
+        }
+    }
+}
+
+// tmp == NULL: report the scratch bytes.  keys_in / vals_in are overwritten (they serve as the second ping-pong buffer).
+hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in,
+                          uint32_t* vals_out, uint32_t n, hipStream_t st) {
+    const uint32_t n_tiles = (n + RS_TILE - 1) / RS_TILE;
+    const size_t need = ((size_t)2 * n + (size_t)256 * n_tiles + 64) * sizeof(uint32_t);
+    if (!tmp) { *tmp_bytes = need; return hipSuccess; }
+    if (*tmp_bytes < need) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    uint32_t* t_keys = reinterpret_cast<uint32_t*>(tmp);
+    uint32_t* t_vals = t_keys + n;
+    uint32_t* hist = t_vals + n;
+    for (int pass = 0; pass < 4; pass++) {
+        const uint32_t *ki = (pass & 1) ? t_keys : keys_in, *vi = (pass & 1) ? t_vals : vals_in;
+        uint32_t *ko = pass == 3 ? keys_out : ((pass & 1) ? keys_in : t_keys), *vo = pass == 3 ? vals_out : ((pass & 1) ? vals_in : t_vals);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(n_tiles), dim3(256), 0, st, ki, n, 8 * pass, hist, n_tiles);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(256), 0, st, hist, 256u * n_tiles);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(n_tiles), dim3(256), 0, st, ki, vi, ko, vo, n, 8 * pass, hist, n_tiles);
+    }
+    return hipGetLastError();
 }
 
 // ---- song_to_song: one persistent launch, grid barrier per step ----

@@ -359,3 +359,27 @@ def test_front_fails_loudly_when_no_seat_is_usable():
     for ln in lines:
         assert ln.startswith("1 True "), ln                       # BLISSGPU_ERR_NO_DEVICE, promptly
         assert "retired, retired" in ln and "HIP device 9" in ln, ln
+
+
+# ---------------------------------------------------------------------------------------------
+# the hand-written stable radix sort behind closest_to_songs (src/playlist.rs:256-270: sort_by_cached_key is stable)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 63, 2048, 2049, 100000, 1 << 20])
+def test_closest_to_songs_sort_is_stable_on_heavy_ties(bliss, n):
+    """one-dimensional songs on an integer grid: thousands of candidates share every distance, so the order is decided by
+    stability alone; sizes around the sort's tile (2048 pairs) and up to 2^20; negative zero and large distances in the
+    keys' high bytes"""
+    import torch
+
+    rng = np.random.default_rng(n)
+    x = rng.integers(-40, 41, n).astype(np.float32)
+    x[rng.random(n) < 0.01] *= 1e6          # a few far candidates: all four key bytes are in play
+    X = np.zeros((n, 3), np.float32)
+    X[:, 0] = x
+    seed = np.zeros((1, 3), np.float32)
+    ctx = bliss.Context(0)
+    order, dist = ctx.closest_to_songs(torch.from_numpy(seed).cuda(), torch.from_numpy(X).cuda(), "euclidean", None, return_distances=True)
+    order, dist = order.cpu().numpy(), dist.cpu().numpy()
+    assert np.array_equal(dist, np.abs(x))                       # sqrt(x^2) is exact on these values
+    assert np.array_equal(order, np.argsort(np.abs(x), kind="stable"))
+    ctx.close()
