@@ -8,14 +8,19 @@ Tolerances (features are normalised to [-1, 1]):
   * the 22 non-tempo features: |gpu - oracle| <= FEATURE_TOL = 1e-5, the reference's own tolerance (observed <= 5e-6); the only
     difference between the two paths is f32 FFT rounding (three register radix-16 passes + real split on the GPU,
     radix-2 c2c in the oracle, rustfft in the reference -- no two of them round alike).  Rolloff is a
-    per-frame integer bin, so one frame flipping by one bin moves its mean by 43.07 Hz / n_frames:
-    the rolloff entries get ROLLOFF_FLIPS such flips on top.
+    per-frame integer bin and the FFT-512 kernel counts it in the reference's summation order (round 3), so the two
+    rolloff entries get NO extra allowance here (ROLLOFF_FLIPS = 0; until round 4 every tolerance carried two flipped
+    frames).  Only spectra with plateaus between partials keep an allowance, where it is demonstrated
+    (test_random_musical_songs_vs_oracle: a frame sitting within an ulp of the threshold ON a plateau).
   * tempo: held to the reference's own 1e-5 (src/song/mod.rs:582-590) for a RECORDED fraction of the songs, every song
     above it listed, and to TEMPO_HARD = 1e-4 for every song.  The fraction is not a convenience: the tempo value ends in
     a parabolic interpolation of an autocorrelation peak that amplifies FFT rounding, and the oracle ITSELF moves by
     more than 1e-5 on 15 of the 1024 bench songs when its FFTs run in f64 instead of f32 (max 5.8e-5); the GPU differs
     from the f32 oracle on 16 of 1024 (max 4.3e-5) and from the f64 oracle on 14 (profiles/r03_full_check_1024songs.json,
-    tests/tools/full_check.py --noise-floor).  No f32 implementation, rustfft included, can be held under that floor.
+    tests/tools/full_check.py --noise-floor).  (Conjecture, not measured here -- there is no Rust toolchain: rustfft's f32
+    transforms would sit at the same floor.)  The allowance is for WHITE NOISE, where the beat tracker's autocorrelation
+    peak is a near-tie by construction: a test of fewer than 34 songs that are not white noise gets none (the musical
+    sets are within 3.6e-7).
   * tuning (discrete, 0.01 semitone bins): must match for every song of the battery; a mismatch would
     be reported, not hidden (white noise makes the histogram argmax a near-tie by construction).
   * tempo differences above TEMPO_HARD are held to a RECORDED expectation (EXPECTED_TEMPO_MISMATCHES = 0 everywhere): a
@@ -34,7 +39,7 @@ FEATURE_TOL = 1e-5   # the reference's own tolerance (src/song/mod.rs:582-590); 
 TEMPO_TOL = 1e-5      # the reference's tolerance; held for >= 1 - TEMPO_NOISE_FRACTION of the songs of a test
 TEMPO_HARD = 1e-4     # every song
 TEMPO_NOISE_FRACTION = 0.03   # recorded: 1.6 % of the 1024 bench songs (GPU vs oracle), 1.5 % oracle-f32 vs oracle-f64
-ROLLOFF_FLIPS = 2     # frames whose rolloff bin may differ by one (observed: 0 on the battery)
+ROLLOFF_FLIPS = 0     # frames whose rolloff bin may differ from the oracle's (the kernel counts in the reference's order)
 EXPECTED_TEMPO_MISMATCHES = 0   # recorded expectation: a change here is a regression to look at, not noise to absorb
 N3MIN = 3969000
 
@@ -78,14 +83,16 @@ def _tol(n_samples, d):
     return tol
 
 
-def _tempo_gate(errs, names):
+def _tempo_gate(errs, names, white_noise=True):
     """tempo |gpu - oracle| of the songs of one test: all <= TEMPO_HARD, and <= TEMPO_TOL (the reference's 1e-5) for all
-    but the recorded noise fraction (at least one song); every song above 1e-5 is listed in the test output"""
+    but the recorded noise fraction -- ceil(3 %), which is at least one song only when the songs are white noise (or the
+    test has 34 or more of them); every song above 1e-5 is listed in the test output"""
     errs = np.asarray(errs, np.float64)
     over = [(names[i], float(errs[i])) for i in np.flatnonzero(errs > TEMPO_TOL)]
     print(f"tempo: {len(errs) - len(over)} of {len(errs)} songs within 1e-5; above it: {over}")
     assert int((errs > TEMPO_HARD).sum()) == EXPECTED_TEMPO_MISMATCHES, over
-    assert len(over) <= max(1, int(np.ceil(TEMPO_NOISE_FRACTION * len(errs)))), over
+    allowed = int(np.ceil(TEMPO_NOISE_FRACTION * len(errs))) if (white_noise or len(errs) >= 34) else 0
+    assert len(over) <= allowed, over
 
 
 def battery(oracle):
@@ -221,7 +228,10 @@ def test_musical_battery_vs_oracle(ctx, oracle):
         tunings.add(round(float(tuning[i]), 2))
     print("\n".join(report))
     assert len(tunings) >= 4, tunings            # the battery does exercise several filter banks
-    _tempo_gate(tempo_err, names)
+    noise = [i for i, k in enumerate(names) if "noise" in k or "amplitude" in k]      # white noise at some gain
+    music = [i for i in range(len(names)) if i not in noise]
+    _tempo_gate([tempo_err[i] for i in music], [names[i] for i in music], white_noise=False)
+    _tempo_gate([tempo_err[i] for i in noise], [names[i] for i in noise])
 
 
 def test_stage_taps_vs_oracle(ctx, oracle, golden_pcm):
@@ -234,7 +244,9 @@ def test_stage_taps_vs_oracle(ctx, oracle, golden_pcm):
         gc, gr, gf = (ctx.debug_fetch(k, i) for k in ("centroid", "rolloff", "flatness"))
         assert len(gc) == len(c) == (len(x) - 512) // 128 + 1
         assert np.abs(gc - c).max() < 2e-2                  # Hz, on values up to 11025
-        assert (np.abs(gr - r) > 1e-3).sum() <= 4           # integer bins x 43.07 Hz: a handful may flip by one
+        assert (np.abs(gr - r) > 1e-3).sum() <= 1           # integer bins x 43.07 Hz, counted in the reference's order: the
+                                                            # golden song's 1 903 frames hold ONE on which the oracle's own f32
+                                                            # and f64 FFTs disagree
         assert np.abs(gf - f).max() < 3e-5                  # log2f/exp2f of the geometric mean: a few ulp on ~0.85
         bd = oracle.BPMDesc().run(x)
         onset, thr = bd.series()

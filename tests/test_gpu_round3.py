@@ -191,13 +191,15 @@ def _config4_lengths(n_total=50000, seed=20260927):
     return rng.integers(30 * 22050, 600 * 22050 + 1, n_total).astype(np.uint64)
 
 
-def _tol(n_samples, d, tempo_tol):
+def _tol(n_samples, d, tempo_tol, flips=0):
+    """the reference's 1e-5 on every feature; `flips` frames on another rolloff bin on top only where a test demonstrates
+    the plateau case (the kernel counts the bins in the reference's summation order: white noise and recordings get none)"""
     tol = np.full(d, FEATURE_TOL)
     tol[0] = tempo_tol
     n_t = (n_samples - 512) // 128 + 1
     flip = 2.0 * (22050.0 / 512.0) / 11025.0 / n_t      # one rolloff bin of one frame (a per-frame integer decision)
-    tol[4] += 2 * flip
-    tol[5] += 2 * flip * np.sqrt(max(n_t, 1)) * 0.5
+    tol[4] += flips * flip
+    tol[5] += flips * flip * np.sqrt(max(n_t, 1)) * 0.5
     return tol
 
 
@@ -579,7 +581,7 @@ def test_random_musical_songs_vs_oracle(bliss, oracle):
     assert np.abs(tuning - otuning).max() < 1e-12 and len(set(np.round(otuning, 2))) >= 40
     assert err[:, 0].max() <= 1e-5, err[:, 0].max()
     others = [j for j in range(1, 23) if j not in (6, 7)]
-    tol = np.stack([_tol(len(s), 23, 1.0) for s in songs])
+    tol = np.stack([_tol(len(s), 23, 1.0, flips=2) for s in songs])
     bad = [(int(i), int(others[k]), float(err[i, others[k]]), float(floor[i, others[k]]))
            for i, k in zip(*np.nonzero(err[:, others] > tol[:, others]))]
     # Rolloff (features 4, 5) is a bin count: where a spectrum has plateaus between partials, the frame whose running

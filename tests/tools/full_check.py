@@ -72,9 +72,21 @@ def main():
         ref64 = oracle_rows()
         O.set_fft_double(False)
         e64 = np.abs(ref.astype(np.float64) - ref64.astype(np.float64))
+        g64 = np.abs(got.astype(np.float64) - ref64.astype(np.float64))
+
+        def side(a, b):   # per-song distances to the f64-FFT oracle: the GPU's against the f32-FFT oracle's own
+            q = lambda v: {"median": float(np.median(v)), "p90": float(np.percentile(v, 90)), "p99": float(np.percentile(v, 99)),
+                           "max": float(v.max())}
+            return {"gpu_to_f64_oracle": q(a), "f32_oracle_to_f64_oracle": q(b),
+                    "songs_where_gpu_is_closer": int((a < b).sum()), "songs_where_f32_oracle_is_closer": int((b < a).sum()),
+                    "gpu_median_at_or_below_f32_oracle_median": bool(np.median(a) <= np.median(b))}
+
         noise = {"what": "oracle with f32 FFTs against the same oracle with f64 FFTs (bo_set_fft_double), same songs",
                  "tempo": tempo_histogram(e64[:, 0]), "max_abs_err_non_tempo": float(e64[:, 1:].max()),
-                 "gpu_vs_f64_oracle_tempo": tempo_histogram(np.abs(got.astype(np.float64) - ref64)[:, 0])}
+                 "gpu_vs_f64_oracle_tempo": tempo_histogram(g64[:, 0]),
+                 "which_side_of_the_floor": {"tempo": side(g64[:, 0], e64[:, 0]), "flatness_mean": side(g64[:, 6], e64[:, 6]),
+                                             "flatness_std": side(g64[:, 7], e64[:, 7]),
+                                             "all_22_non_tempo_features_max": side(g64[:, 1:].max(axis=1), e64[:, 1:].max(axis=1))}}
     res = {"songs": n, "samples_per_song": N, "oracle_seconds": round(time.perf_counter() - t0, 1),
            "tempo_gpu_vs_oracle": tempo_histogram(err[:, 0]), "tempo_noise_floor": noise,
            "max_abs_err_non_tempo": float(err[:, 1:].max()),
