@@ -15,7 +15,7 @@ OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_NAN, ERR_RCCL, ERR_TIMEOUT
 SAMPLE_F32, SAMPLE_S16 = 0, 1
 SONG_OK, SONG_TOO_SHORT = 0, 1
 METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_MAHALANOBIS = 0, 1, 2
-OPT_SERIAL, OPT_TAIL_MODE, OPT_PIPELINE_CHUNKS, OPT_CAND_BUDGET, OPT_ROLLOFF_EXACT_ALL, OPT_DEBUG_CHROMA = 0, 1, 2, 3, 4, 5
+OPT_SERIAL, OPT_TAIL_MODE, OPT_PIPELINE_CHUNKS, OPT_CAND_BUDGET, OPT_ROLLOFF_EXACT_ALL, OPT_DEBUG_CHROMA, OPT_TAIL_SPLIT = 0, 1, 2, 3, 4, 5, 6
 
 _f32p = C.POINTER(C.c_float)
 _f64p = C.POINTER(C.c_double)

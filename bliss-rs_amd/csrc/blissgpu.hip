@@ -320,6 +320,7 @@ int blissgpu_ctx_set_option(blissgpu_ctx* c, int option, int64_t value) {
         case BLISSGPU_OPT_PIPELINE_CHUNKS: c->pipeline_chunks = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); break;
         case BLISSGPU_OPT_ROLLOFF_EXACT_ALL: c->rolloff_exact_all = value != 0; break;
         case BLISSGPU_OPT_DEBUG_CHROMA: c->debug_chroma = value != 0; break;
+        case BLISSGPU_OPT_TAIL_SPLIT: c->tail_split = (int)value; break;
         case BLISSGPU_OPT_CAND_BUDGET: c->cand_budget = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 714)); break;
         default: return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_set_option", "unknown option");
     }

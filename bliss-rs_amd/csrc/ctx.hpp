@@ -78,6 +78,10 @@ struct ChunkSlot {
     DevBuf<uint8_t> desc;        // SongDesc[] + tile prefix arrays
     PinnedBuf<uint8_t> h_desc;   // pinned staging of desc
     hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_stft = nullptr, ev_sel = nullptr, ev_tune = nullptr, ev_sum = nullptr, ev_chroma = nullptr;
+    static constexpr int MAX_PIECES = 8;
+    hipEvent_t ev_piece[MAX_PIECES] = {};  // the tuning estimate of piece k of the songs is in (split tail)
+    int pieces = 0;                        // > 0: the tail of the chunk in flight runs in these pieces
+    bg::SongRange piece[MAX_PIECES]{};
     hipEvent_t ev_desc = nullptr;  // recorded on the main stream after the descriptor copy: the staging area is free
     hipEvent_t ev_free = nullptr;  // recorded on the aux stream after the row assembly: the slot is free
     bool used = false;
@@ -119,6 +123,7 @@ struct blissgpu_ctx {
                                        // per-song tails have a fixed latency per launch, so more chunks than memory needs lose)
     hipEvent_t ev_interop = nullptr;
     bool rolloff_exact_all = false;    // BLISSGPU_OPT_ROLLOFF_EXACT_ALL (tests)
+    int tail_split = 0;                // BLISSGPU_OPT_TAIL_SPLIT: one-chunk batches run the tuning estimate + contraction in two halves
     bool debug_chroma = false;         // BLISSGPU_OPT_DEBUG_CHROMA (tests): keep the chroma matrix / interval means of the last chunk
     bool serial = false;               // BLISSGPU_OPT_SERIAL: single stream (clean per-kernel timings)
     uint64_t ws_limit = 0;             // bytes per chunk slot (set from the free device memory at creation)

@@ -181,10 +181,13 @@ void launch_rolloff_fix(const Batch&, const Workspace&, uint64_t total_t, hipStr
 void launch_onset(const Batch&, const Workspace&, hipStream_t);
 void launch_beat(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
 void launch_stft8192(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
-void launch_tune_select(const Batch&, const Workspace&, hipStream_t);
-void launch_tune_pass2(const Batch&, const Workspace&, hipStream_t);
-void launch_tune_final(const Batch&, const Workspace&, hipStream_t);
-void launch_chroma(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
+// a contiguous range of a chunk's songs [s0, s1) with the tile / workgroup ranges that belong to it in pfx_ct / pfx_cw
+// units (the tuning estimate and the contraction of a one-chunk batch run in two halves; NULL = the whole chunk)
+struct SongRange { uint32_t s0, s1, ct0, ct1, cw0, cw1; };
+void launch_tune_select(const Batch&, const Workspace&, hipStream_t, const SongRange* r = nullptr);
+void launch_tune_pass2(const Batch&, const Workspace&, hipStream_t, const SongRange* r = nullptr);
+void launch_tune_final(const Batch&, const Workspace&, hipStream_t, const SongRange* r = nullptr);
+void launch_chroma(const Batch&, const Workspace&, const DeviceTables&, hipStream_t, const SongRange* r = nullptr);
 void launch_summary(const Batch&, const Workspace&, hipStream_t);
 void launch_finalize(const Batch&, const Workspace&, uint32_t features_version, float* d_out, int32_t* d_status,
                      int32_t* dbg_tuning, uint32_t* dbg_nbpms, hipStream_t);

@@ -621,10 +621,11 @@ void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, 
 __global__ __launch_bounds__(256) void tune_select_kernel(const SongDesc* __restrict__ songs,
                                                           const uint32_t* __restrict__ h1,
                                                           TuningState* __restrict__ tuning,
-                                                          uint32_t* __restrict__ cand_cursor, uint32_t cand_pool) {
+                                                          uint32_t* __restrict__ cand_cursor, uint32_t cand_pool,
+                                                          uint32_t first_song) {
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t s_total, s_blo, s_bhi;
-    const uint32_t s = blockIdx.x;
+    const uint32_t s = blockIdx.x + first_song;
     const int tid = threadIdx.x;
     TuningState* ts = tuning + s;
     auto no_peaks = [&]() {
@@ -689,10 +690,11 @@ __global__ __launch_bounds__(256) void tune_select_kernel(const SongDesc* __rest
     }
 }
 
-void launch_tune_select(const Batch& b, const Workspace& w, hipStream_t st) {
-    if (b.n_songs == 0) return;
-    hipLaunchKernelGGL(tune_select_kernel, dim3(b.n_songs), dim3(256), 0, st, b.songs, w.h1, w.tuning, w.cand_cursor,
-                       w.cand_cap);
+void launch_tune_select(const Batch& b, const Workspace& w, hipStream_t st, const SongRange* r) {
+    const uint32_t s0 = r ? r->s0 : 0, s1 = r ? r->s1 : b.n_songs;
+    if (s1 <= s0) return;
+    hipLaunchKernelGGL(tune_select_kernel, dim3(s1 - s0), dim3(256), 0, st, b.songs, w.h1, w.tuning, w.cand_cursor,
+                       w.cand_cap, s0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -715,12 +717,13 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
                                                          TuningState* __restrict__ tuning,
                                                          uint32_t* __restrict__ hist100,
                                                          double* __restrict__ cand_mag,
-                                                         uint8_t* __restrict__ cand_pb) {
+                                                         uint8_t* __restrict__ cand_pb, uint32_t first_tile) {
     __shared__ uint32_t hist[N_TUNING];
     __shared__ uint32_t slow_list[4][P2_SLOW_CAP];  // (frame slot << 16) | centre bin
-    const uint32_t s = find_segment(pfx_ct, n_songs, blockIdx.x);
+    const uint32_t bx = blockIdx.x + first_tile;
+    const uint32_t s = find_segment(pfx_ct, n_songs, bx);
     const SongDesc sd = songs[s];
-    const uint32_t tile = blockIdx.x - pfx_ct[s];
+    const uint32_t tile = bx - pfx_ct[s];
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     TuningState* ts = tuning + s;
     const uint32_t b_lo = ts->b_lo, b_hi = ts->b_hi;
@@ -810,10 +813,11 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
     if (tid < N_TUNING && hist[tid]) atomicAdd(&hist100[(size_t)s * N_TUNING + tid], hist[tid]);
 }
 
-void launch_tune_pass2(const Batch& b, const Workspace& w, hipStream_t st) {
-    if (b.tiles_ct == 0) return;
-    hipLaunchKernelGGL(tune_pass2_kernel, dim3(b.tiles_ct), dim3(256), 0, st, b.songs, b.n_songs, b.pfx_ct, w.spec,
-                       w.frame_max, w.peak_rec, w.peak_cnt, w.tuning, w.hist100, w.cand_mag, w.cand_pb);
+void launch_tune_pass2(const Batch& b, const Workspace& w, hipStream_t st, const SongRange* r) {
+    const uint32_t t0 = r ? r->ct0 : 0, t1 = r ? r->ct1 : b.tiles_ct;
+    if (t1 <= t0) return;
+    hipLaunchKernelGGL(tune_pass2_kernel, dim3(t1 - t0), dim3(256), 0, st, b.songs, b.n_songs, b.pfx_ct, w.spec,
+                       w.frame_max, w.peak_rec, w.peak_cnt, w.tuning, w.hist100, w.cand_mag, w.cand_pb, t0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -878,11 +882,11 @@ __global__ __launch_bounds__(256) void tune_final_kernel(const SongDesc* __restr
                                                          const float* __restrict__ spec,
                                                          const float* __restrict__ frame_max,
                                                          const uint32_t* __restrict__ peak_rec,
-                                                         const uint32_t* __restrict__ peak_cnt) {
+                                                         const uint32_t* __restrict__ peak_cnt, uint32_t first_song) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_digit, s_rank, s_cnt_le, s_wave[4];
     __shared__ unsigned long long s_min_gt;
-    const uint32_t s = blockIdx.x;
+    const uint32_t s = blockIdx.x + first_song;
     const int tid = threadIdx.x;
     TuningState* ts = tuning + s;
     const SongDesc sd = songs[s];
@@ -973,10 +977,11 @@ __global__ __launch_bounds__(256) void tune_final_kernel(const SongDesc* __restr
     }
 }
 
-void launch_tune_final(const Batch& b, const Workspace& w, hipStream_t st) {
-    if (b.n_songs == 0) return;
-    hipLaunchKernelGGL(tune_final_kernel, dim3(b.n_songs), dim3(256), 0, st, b.songs, w.tuning, w.hist100,
-                       w.cand_mag, w.cand_pb, w.spec, w.frame_max, w.peak_rec, w.peak_cnt);
+void launch_tune_final(const Batch& b, const Workspace& w, hipStream_t st, const SongRange* r) {
+    const uint32_t s0 = r ? r->s0 : 0, s1 = r ? r->s1 : b.n_songs;
+    if (s1 <= s0) return;
+    hipLaunchKernelGGL(tune_final_kernel, dim3(s1 - s0), dim3(256), 0, st, b.songs, w.tuning, w.hist100,
+                       w.cand_mag, w.cand_pb, w.spec, w.frame_max, w.peak_rec, w.peak_cnt, s0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1011,12 +1016,13 @@ __device__ __forceinline__ double interval_feature(const double (&c)[12]) {
 __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict__ songs, uint32_t n_songs, const uint32_t* __restrict__ pfx_cw,
                               const uint32_t* __restrict__ pfx_ct, const float* __restrict__ spec,
                               const double* __restrict__ bank, const TuningState* __restrict__ tuning,
-                              double* __restrict__ chroma_part, double* __restrict__ dbg_chroma);
+                              double* __restrict__ chroma_part, double* __restrict__ dbg_chroma, uint32_t first_wg);
 
-void launch_chroma(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
-    if (b.tiles_cw == 0) return;
-    hipLaunchKernelGGL(chroma_kernel, dim3(b.tiles_cw), dim3(256), 0, st, b.songs, b.n_songs, b.pfx_cw, b.pfx_ct, w.spec,
-                       t.chroma_bank, w.tuning, w.chroma_part, w.dbg_chroma);
+void launch_chroma(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st, const SongRange* r) {
+    const uint32_t g0 = r ? r->cw0 : 0, g1 = r ? r->cw1 : b.tiles_cw;
+    if (g1 <= g0) return;
+    hipLaunchKernelGGL(chroma_kernel, dim3(g1 - g0), dim3(256), 0, st, b.songs, b.n_songs, b.pfx_cw, b.pfx_ct, w.spec,
+                       t.chroma_bank, w.tuning, w.chroma_part, w.dbg_chroma, g0);
 }
 
 // (a probe translation unit that brings its own contraction -- tests/tools/probes/handpipe -- defines this before it
@@ -1031,12 +1037,13 @@ __global__ __launch_bounds__(256) void chroma_kernel(const SongDesc* __restrict_
                                                      const double* __restrict__ bank,
                                                      const TuningState* __restrict__ tuning,
                                                      double* __restrict__ chroma_part,
-                                                     double* __restrict__ dbg_chroma) {
+                                                     double* __restrict__ dbg_chroma, uint32_t first_wg) {
     __shared__ double tile_c[4][4][16][13];
-    const uint32_t s = find_segment(pfx_cw, n_songs, blockIdx.x);
+    const uint32_t bx = blockIdx.x + first_wg;
+    const uint32_t s = find_segment(pfx_cw, n_songs, bx);
     const SongDesc sd = songs[s];
     const int lane = lane_id(), wave = wave_id();
-    const uint32_t tile64 = (blockIdx.x - pfx_cw[s]) * 4 + wave;   // 64-frame tile of this wave
+    const uint32_t tile64 = (bx - pfx_cw[s]) * 4 + wave;   // 64-frame tile of this wave
     const uint32_t n_tiles = pfx_ct[s + 1] - pfx_ct[s];
     if (tile64 >= n_tiles) return;  // wave-uniform; no workgroup barriers below
     const int i16 = lane & 15, g = lane >> 4;

@@ -113,6 +113,7 @@ int ensure_slot_events(ChunkSlot& s) {
     if (s.ev_free) return BLISSGPU_OK;
     hipEvent_t* evs[] = {&s.ev_start, &s.ev_fork, &s.ev_stft, &s.ev_sel, &s.ev_tune, &s.ev_sum, &s.ev_chroma, &s.ev_desc, &s.ev_free};
     for (hipEvent_t* e : evs) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t& e : s.ev_piece) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return BLISSGPU_OK;
 }
 
@@ -239,6 +240,40 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
         HIP_TRY(hipEventRecord(slot.ev_stft, st));
         HIP_TRY(hipStreamWaitEvent(sc, slot.ev_stft, 0));
     }
+    // Split tail (BLISSGPU_OPT_TAIL_SPLIT = P, one-chunk batches only): the songs are cut into P pieces of about equal
+    // numbers of chroma tiles; tuning(0) -> [contraction(0) on the main stream] beside {tuning(1), beat tracker} ->
+    // contraction(1) beside tuning(2) ...: only the first piece's tuning estimate stands between the FFT-8192 kernel and
+    // the contraction.
+    slot.pieces = 0;
+    if (multi && only_chunk && c->tail_split > 1 && ns >= 2) {
+        const int want = std::min<int>(std::min<int>(c->tail_split, ChunkSlot::MAX_PIECES), (int)ns);
+        uint32_t s0 = 0;
+        for (int k = 0; k < want && s0 < ns; k++) {
+            uint32_t s1 = s0 + 1;
+            const uint64_t goal = (uint64_t)pfx_ct[ns] * (uint64_t)(k + 1) / (uint64_t)want;
+            while (s1 < ns && (k == want - 1 || pfx_ct[s1] < goal)) s1++;
+            slot.piece[slot.pieces++] = SongRange{s0, s1, pfx_ct[s0], pfx_ct[s1], pfx_cw[s0], pfx_cw[s1]};
+            s0 = s1;
+        }
+        if (slot.pieces < 2) slot.pieces = 0;
+    }
+    if (slot.pieces) {
+        for (int k = 0; k < slot.pieces; k++) {
+            { Prof p(c, K_TUNE_SELECT, sc); launch_tune_select(b, w, sc, &slot.piece[k]); }
+            if (k == 1 && beat_late) {  // behind a tune_select, as in the unsplit schedule
+                HIP_TRY(hipEventRecord(slot.ev_sel, sc));
+                HIP_TRY(hipStreamWaitEvent(sb, slot.ev_sel, 0));
+                Prof p(c, K_BEAT, sb);
+                launch_beat(b, w, c->tables, sb);
+            }
+            { Prof p(c, K_TUNE_PASS2, sc); launch_tune_pass2(b, w, sc, &slot.piece[k]); }
+            { Prof p(c, K_TUNE_FINAL, sc); launch_tune_final(b, w, sc, &slot.piece[k]); }
+            HIP_TRY(hipEventRecord(slot.ev_piece[k], sc));
+        }
+        HIP_TRY(hipGetLastError());
+        slot.back_pending = true;
+        return BLISSGPU_OK;
+    }
     { Prof p(c, K_TUNE_SELECT, sc); launch_tune_select(b, w, sc); }
     if (beat_late) {
         // behind tune_select, not beside it: a kernel with resident workgroups on every CU holds that 20 us kernel (the
@@ -263,8 +298,17 @@ int chunk_back(blissgpu_ctx* c, ChunkSlot& slot, uint32_t features_version, floa
     slot.back_pending = false;
     hipStream_t st = c->stream, sb = c->serial ? c->stream : c->aux_stream;
     const bool multi = !c->serial;
-    if (multi) HIP_TRY(hipStreamWaitEvent(st, slot.ev_tune, 0));
-    { Prof p(c, K_CHROMA); launch_chroma(slot.batch, slot.ws, c->tables, st); }
+    if (slot.pieces) {
+        for (int k = 0; k < slot.pieces; k++) {
+            HIP_TRY(hipStreamWaitEvent(st, slot.ev_piece[k], 0));
+            Prof p(c, K_CHROMA);
+            launch_chroma(slot.batch, slot.ws, c->tables, st, &slot.piece[k]);
+        }
+    } else {
+        if (multi) HIP_TRY(hipStreamWaitEvent(st, slot.ev_tune, 0));
+        Prof p(c, K_CHROMA);
+        launch_chroma(slot.batch, slot.ws, c->tables, st);
+    }
     if (multi) {
         HIP_TRY(hipEventRecord(slot.ev_chroma, st));
         HIP_TRY(hipStreamWaitEvent(sb, slot.ev_chroma, 0));  // aux already holds the chunk's summaries and beat tracker
@@ -284,6 +328,8 @@ void scheduler_release(blissgpu_ctx* c) {
         s.slab.release(); s.desc.release(); s.h_desc.release();
         hipEvent_t evs[] = {s.ev_start, s.ev_fork, s.ev_stft, s.ev_sel, s.ev_tune, s.ev_sum, s.ev_chroma, s.ev_desc, s.ev_free};
         for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : s.ev_piece)
             if (e) (void)hipEventDestroy(e);
         s = ChunkSlot{};
     }

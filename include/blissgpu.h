@@ -92,6 +92,9 @@ int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
 #define BLISSGPU_OPT_CAND_BUDGET 3      /* tuning-candidate pool: slots per chroma frame (default 48; 0 starves the pool) */
 #define BLISSGPU_OPT_ROLLOFF_EXACT_ALL 4 /* 1: every frame's rolloff bin through the reference-order pass, not only the frames
                                            the FFT-512 kernel cannot prove (tests: both must give the same rows) */
+#define BLISSGPU_OPT_TAIL_SPLIT 6       /* one-chunk batches: P >= 2 = the tuning estimate and the contraction run in P pieces of the
+                                           songs (at most 8), the contraction of piece k beside the tuning estimate of piece
+                                           k + 1; 0 / 1 = unsplit (default: see DESIGN.md section 3b) */
 #define BLISSGPU_OPT_DEBUG_CHROMA 5     /* 1: the contraction also keeps chroma_stft's matrix and the assembly the interval
                                            means of the last chunk for the CHROMA / INTERVAL taps below (96 B per frame) */
 int blissgpu_ctx_set_option(blissgpu_ctx *ctx, int option, int64_t value);

@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
         const uint64_t m = argc > 3 ? (uint64_t)std::atoll(argv[3]) : 100000;
         const int reps = argc > 4 ? std::atoi(argv[4]) : 3;
         SYM(blissgpu_last_error) SYM(blissgpu_ctx_create) SYM(blissgpu_ctx_destroy) SYM(blissgpu_malloc) SYM(blissgpu_free)
-        SYM(blissgpu_memcpy_h2d) SYM(blissgpu_pairwise_device) SYM(blissgpu_ctx_synchronize)
+        SYM(blissgpu_memcpy_h2d) SYM(blissgpu_memcpy_d2h) SYM(blissgpu_pairwise_device) SYM(blissgpu_ctx_synchronize)
         blissgpu_ctx* c = nullptr;
         OK(p_blissgpu_ctx_create(0, &c));
         std::vector<float> h(m * 23);
@@ -46,8 +46,18 @@ int main(int argc, char** argv) {
             for (int r = 0; r < reps; r++) OK(p_blissgpu_pairwise_device(c, dA, m, rhs, m, 23, BLISSGPU_METRIC_EUCLIDEAN, nullptr, dD, m));
             OK(p_blissgpu_ctx_synchronize(c));
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
-            std::printf("pairwise %s n=%llu ms=%.3f pairs_per_s=%.4g GBps=%.0f\n", general ? "general(A!=B)" : "self(A==B)",
-                        (unsigned long long)m, ms, (double)m * m / (ms * 1e-3), (4.0 * m * m + 8.0 * 23 * m) / (ms * 1e-3) / 1e9);
+            // hash of 64 whole rows spread over the matrix (two builds that agree bit for bit print the same value)
+            uint64_t hash = 1469598103934665603ull;
+            std::vector<float> row(m);
+            for (int q = 0; q < 64; q++) {
+                const uint64_t i = (uint64_t)q * (m - 1) / 63;
+                OK(p_blissgpu_memcpy_d2h(c, row.data(), dD + i * m, m * 4));
+                const unsigned char* b = (const unsigned char*)row.data();
+                for (size_t z = 0; z < m * 4; z++) { hash ^= b[z]; hash *= 1099511628211ull; }
+            }
+            std::printf("pairwise %s n=%llu ms=%.3f pairs_per_s=%.4g GBps=%.0f hash=%016llx\n", general ? "general(A!=B)" : "self(A==B)",
+                        (unsigned long long)m, ms, (double)m * m / (ms * 1e-3), (4.0 * m * m + 8.0 * 23 * m) / (ms * 1e-3) / 1e9,
+                        (unsigned long long)hash);
         }
         p_blissgpu_free(dA); p_blissgpu_free(dB); p_blissgpu_free(dD);
         p_blissgpu_ctx_destroy(c);
@@ -67,6 +77,7 @@ int main(int argc, char** argv) {
     if (const char* e = std::getenv("KBENCH_WS_LIMIT_MB")) OK(p_blissgpu_ctx_set_workspace_limit(c, (uint64_t)std::atoll(e) << 20));
     if (const char* e = std::getenv("KBENCH_SERIAL")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_SERIAL, std::atoi(e)));
     if (const char* e = std::getenv("KBENCH_TAIL_MODE")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_TAIL_MODE, std::atoi(e)));
+    if (const char* e = std::getenv("KBENCH_TAIL_SPLIT")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_TAIL_SPLIT, std::atoi(e)));
     if (const char* e = std::getenv("KBENCH_PIPELINE_CHUNKS")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_PIPELINE_CHUNKS, std::atoi(e)));
     std::vector<uint64_t> offs(n), lens(n);
     uint64_t total = 0;
