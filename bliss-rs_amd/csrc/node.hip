@@ -85,6 +85,7 @@ struct blissgpu_node {
     int n = 0;
     bool loopback = false;              // some device ordinal appears twice: gather by device-to-device copies, no RCCL
     std::vector<hipEvent_t> ev_rows;    // per rank: its local rows are in send[r] (loopback gather)
+    std::vector<hipEvent_t> ev_read;    // per rank: it has copied every rank's send buffer (loopback gather)
     std::vector<int> devices;
     std::vector<blissgpu_ctx*> ctx;
     std::vector<ncclComm_t> comm;
@@ -155,6 +156,15 @@ int gather_rows(blissgpu_node* nd) {
                 if (q != r) HIP_TRY(hipStreamWaitEvent(c->stream, nd->ev_rows[q], 0));
                 HIP_TRY(hipMemcpyAsync(nd->recv[r].p + (size_t)q * block, nd->send[q].p, block * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
             }
+            HIP_TRY(hipEventRecord(nd->ev_read[r], c->stream));  // rank r has read every send buffer
+        }
+        // the owner of a send buffer may only overwrite it (the next call's memset and row writes) once every OTHER rank's
+        // copy out of it has run: without this the next node call raced with the previous gather unless the caller
+        // synchronised in between
+        for (int q = 0; q < R; q++) {
+            HIP_TRY(hipSetDevice(nd->ctx[q]->device));
+            for (int r = 0; r < R; r++)
+                if (r != q) HIP_TRY(hipStreamWaitEvent(nd->ctx[q]->stream, nd->ev_read[r], 0));
         }
     } else {
         // single-process multi-device collectives must be issued inside one group; the group is closed on every path
@@ -236,6 +246,7 @@ int blissgpu_node_create(int n_devices, const int* devices, blissgpu_node** out)
     nd->loopback = loopback;
     nd->devices = devs;
     nd->ev_rows.assign(n_devices, nullptr);
+    nd->ev_read.assign(n_devices, nullptr);
     nd->ctx.assign(n_devices, nullptr);
     nd->comm.assign(n_devices, nullptr);
     nd->send.resize(n_devices); nd->recv.resize(n_devices); nd->full.resize(n_devices); nd->block.resize(n_devices);
@@ -244,6 +255,7 @@ int blissgpu_node_create(int n_devices, const int* devices, blissgpu_node** out)
     for (int r = 0; r < n_devices && !rc; r++) {
         hipError_t e = hipSetDevice(nd->devices[r]);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&nd->ev_rows[r], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&nd->ev_read[r], hipEventDisableTiming);
         if (e != hipSuccess) rc = fail(BLISSGPU_ERR_HIP, "hipEventCreate", hipGetErrorString(e));
     }
     if (!rc && !loopback) {
@@ -261,6 +273,7 @@ int blissgpu_node_destroy(blissgpu_node* nd) {
         if (nd->ctx[r]) { (void)hipSetDevice(nd->ctx[r]->device); (void)hipStreamSynchronize(nd->ctx[r]->stream); }
         if (nd->comm[r]) (void)g_rccl.CommDestroy(nd->comm[r]);
         if (nd->ev_rows[r]) (void)hipEventDestroy(nd->ev_rows[r]);
+        if (nd->ev_read[r]) (void)hipEventDestroy(nd->ev_read[r]);
         nd->send[r].release(); nd->recv[r].release(); nd->full[r].release(); nd->block[r].release();
         nd->perm[r].release(); nd->dm[r].release();
         if (nd->ctx[r]) blissgpu_ctx_destroy(nd->ctx[r]);

@@ -205,7 +205,12 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
     {
         // the exact rolloff pass's record (its entries borrow the spectrogram + peak records, see carve)
         RollFix rf{};
-        rf.cap = (uint32_t)std::min<uint64_t>(t.tot_t, w.roll_fix_bytes / (257 * 4));  // = tot_t (see carve)
+        // Every timbral frame of the chunk must have an entry of its own: a frame turned away would keep the unproven
+        // fast-path bin without a sign.  The static_assert in carve() proves the bytes-per-sample ratio; this is the
+        // per-chunk proof that the rounding of every song's frame counts (many near-minimum-length songs) does not eat it.
+        if ((uint64_t)w.roll_fix_bytes / (257 * 4) < t.tot_t)
+            return fail(BLISSGPU_ERR_INVALID, "chunk_front", "internal: the borrowed stretch cannot hold one exact-rolloff entry per timbral frame");
+        rf.cap = (uint32_t)t.tot_t;
         rf.mags = w.spec;
         rf.frame = reinterpret_cast<uint32_t*>(w.spec + (size_t)rf.cap * 256);
         rf.cursor = w.roll_fix_cursor;

@@ -392,3 +392,52 @@ def test_rolloff_guard_on_emulated_summation_orders():
         if name == "white":
             assert 0.01 < risky.mean() < 0.035, risky.mean()
     assert disagreements > 20       # the engineered ties do make the orders disagree: the check is not vacuous
+
+
+def test_rust_binding_declarations_match_the_header():
+    """bindings/rust/gpu.rs cannot be compiled here (no rustc in the image); its `extern "C"` block is held to
+    include/blissgpu.h declaration by declaration instead -- name, argument count, every argument type, the return type."""
+    import re
+
+    header = open(os.path.join(ROOT, "include", "blissgpu.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    cdecl = {}
+    for m in re.finditer(r"\n((?:const\s+)?[a-z_0-9]+\s*\**)\s*(blissgpu_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        cdecl[name] = (" ".join(ret.split()), [a.strip() for a in args.split(",")] if args.strip() not in ("", "void") else [])
+
+    def rust_of(ctype):
+        t = " ".join(ctype.replace("*", " * ").split())
+        t = re.sub(r"\s+[A-Za-z_][A-Za-z_0-9]*$", "", t) if not t.endswith("*") and len(t.split()) > 1 and t.split()[-1] not in (
+            "int", "float", "double", "char", "void", "uint64_t", "uint32_t", "int64_t", "int32_t", "int16_t") else t
+        base = {"int": "c_int", "float": "f32", "double": "f64", "uint64_t": "u64", "uint32_t": "u32", "int64_t": "i64", "int32_t": "i32",
+                "int16_t": "i16", "void": "c_void", "char": "c_char", "blissgpu_ctx": "blissgpu_ctx", "blissgpu_node": "blissgpu_node"}
+        toks = t.split()
+        const = toks[0] == "const"
+        if const:
+            toks = toks[1:]
+        stars = toks.count("*")
+        ty = base[toks[0]]
+        if stars == 0:
+            return ty
+        out = ("*const " if const else "*mut ") + ty
+        for _ in range(stars - 1):
+            out = "*mut " + out
+        return out
+
+    rs = open(os.path.join(ROOT, "bindings", "rust", "gpu.rs")).read()
+    block = rs[rs.index('extern "C" {'):]
+    block = block[:block.index("\n    }\n")]
+    block = re.sub(r"//[^\n]*", "", block)
+    n = 0
+    for m in re.finditer(r"pub fn (blissgpu_[a-z0-9_]+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+        name, args, ret = m.group(1), m.group(2), (m.group(3) or "()").strip()
+        assert name in cdecl, f"{name} is not declared in include/blissgpu.h"
+        cret, cargs = cdecl[name]
+        rargs = [" ".join(a.split(":", 1)[1].split()) for a in args.split(",") if a.strip()]
+        assert len(rargs) == len(cargs), (name, rargs, cargs)
+        for ra, ca in zip(rargs, cargs):
+            assert ra == rust_of(ca), (name, ra, ca, rust_of(ca))
+        assert ret == rust_of(cret), (name, ret, cret)
+        n += 1
+    assert n >= 30, n
