@@ -325,11 +325,13 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
             ss_acc = 0.0f;
             zc_acc = 0;
             // tempo frame j = (k-1)/2 : SpecFlux over bins 0..256 (src/aubio.rs:455-467)
+            // `if (cur > prev) f += cur - prev` as f += max(cur - prev, 0): the same sum bit for bit (a positive difference
+            // of two floats is never rounded to zero, adding +0 to a non-negative f changes nothing, and max drops a NaN
+            // difference exactly as the comparison does) in three instructions per bin instead of four
             float f = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 16; e++)
-                if (cur.m[e] > prev.m[e]) f += cur.m[e] - prev.m[e];
-            if (l == 0 && cur.nyq > prev.nyq) f += cur.nyq - prev.nyq;
+            for (int e = 0; e < 16; e++) f += fmaxf(cur.m[e] - prev.m[e], 0.0f);
+            if (l == 0) f += fmaxf(cur.nyq - prev.nyq, 0.0f);
             f = row16_sum(f);
             if (J == 1 && share && k == k_begin + 1) {
                 // no previous tempo frame here: hand this frame's magnitudes to the group before
@@ -380,11 +382,12 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
                 signs = __builtin_amdgcn_alignbit(signs, __float_as_uint(d), 31);
                 asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(near) : "v"(d0), "v"(d));
             }
-            const int c = row16_sum((int)__popc(signs));
             // not (near > guard): also catches NaN; totals in the denormal range have no relative bound; a frame of digital
             // silence is 0 in either order
             const bool risky = ROLLOFF_EXACT_ALL || (cum_total != 0.0f && (!(near > cum_total * ROLL_GUARD) || cum_total < 1e-30f));
-            // geometric_mean (src/utils.rs:101-117): groups of 8 in f64, exponents and mantissas apart
+            // geometric_mean (src/utils.rs:101-117): groups of 8 in f64, exponents and mantissas apart.  (f64 multiplies and
+            // conversions issue at the f32 rate on this chip; the same split done on the f32 bit patterns -- shift, and-or,
+            // f32 product -- needs MORE instructions: +59 over the kernel, measured by count in round 4 and dropped.)
             int expo = 0, zero = 0;
             double mant = 1.0;
 #pragma unroll
@@ -399,8 +402,10 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
                 expo += (int)(bits >> 52);
                 mant *= __longlong_as_double((long long)((bits & 0xFFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
             }
-            const int any_zero = row16_sum(zero);
-            const int exps = row16_sum(expo);
+            // one reduction for the three integers: rolloff count (<= 256: 9 bits) | lanes with a zero group (<= 16: 5 bits) |
+            // biased f64 exponents (two per lane, <= 16 x 4094: 16 bits)
+            const int red = row16_sum((int)((uint32_t)__popc(signs) | ((uint32_t)zero << 9) | ((uint32_t)expo << 14)));
+            const int c = red & 511, any_zero = (red >> 9) & 31, exps = (int)((uint32_t)red >> 14);
             mant = row16_prod(mant);
             // The scalar tail (two divisions, log2, exp2, the normalisations: ~40 instructions) would run identically on all
             // 16 lanes of the group; instead lane k mod 16 keeps the reduced sums of frame k and every 16 frames each lane
@@ -475,10 +480,10 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const float c = halo[grp + 1][16 * e + l];
-            if (c > A.m[e]) f += c - A.m[e];
+            f += fmaxf(c - A.m[e], 0.0f);
         }
         const float cn = halo[grp + 1][256];
-        if (l == 0 && cn > A.nyq) f += cn - A.nyq;
+        if (l == 0) f += fmaxf(cn - A.nyq, 0.0f);
         f = row16_sum(f);
         if (l == 0 && q < (long)sd.n_b) flux[sd.b_off + q] = f;
     }
