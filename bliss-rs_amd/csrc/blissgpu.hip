@@ -536,7 +536,8 @@ int blissgpu_closest_to_songs_device(blissgpu_ctx* c, const float* d_seeds, uint
         launch_set_distance(d_seeds, n_seeds, d_cand, n, d, metric, d_M, d_dist, keys_in, idx_in, c->pl_sync.p + 1, c->stream);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(sort_pairs_u32(c->pl_tmp.p, &tmp_bytes, keys_in, keys_out, idx_in, d_order, n32, c->stream));
+    HIP_TRY(sort_pairs_u32(c->pl_tmp.p, &tmp_bytes, keys_in, keys_out, idx_in, d_order, n32, c->stream, c->pl_sync.p + 2,
+                           (uint32_t)std::max(1, c->n_cus)));
     return nan_check(c, c->pl_sync.p + 1, "blissgpu_closest_to_songs_device");
 }
 

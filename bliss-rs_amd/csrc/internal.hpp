@@ -200,8 +200,9 @@ void launch_pair_distance(const float* a, const float* b, uint32_t d, int metric
 void launch_set_distance(const float* seeds, uint32_t n_seeds, const float* cand, uint64_t n, uint32_t d, int metric,
                          const float* M, float* dist, uint32_t* keys, uint32_t* idx, uint32_t* nan_flag, hipStream_t st);
 // stable radix sort of (key, value) pairs; tmp == NULL reports the scratch bytes; keys_in / vals_in are scratch afterwards
+// (sync: one zeroed word -> the single-launch form when the tiles fit max_coresident workgroups; NULL: one launch per step)
 hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in,
-                          uint32_t* vals_out, uint32_t n, hipStream_t st);
+                          uint32_t* vals_out, uint32_t n, hipStream_t st, uint32_t* sync = nullptr, uint32_t max_coresident = 0);
 void launch_song_to_song(const float* seeds, uint32_t n_seeds, const float* cand, uint32_t n, uint32_t d, int metric,
                          const float* M, uint32_t* order, unsigned long long* slots, uint32_t* sync, uint32_t grid,
                          hipStream_t st);

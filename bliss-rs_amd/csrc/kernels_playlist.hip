@@ -149,15 +149,15 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                            uint32_t n, int shift, const uint32_t* __restrict__ offs,
-                                                            uint32_t n_tiles) {
-    __shared__ uint32_t wcount[4][256];   // pairs with digit d the wavefront has placed so far; later: its first output slot
+// one tile of the scatter; `tile_first[d]` (thread d's argument) = the output slot of the tile's first pair with digit d
+__device__ __forceinline__ void radix_scatter_tile(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
+                                                   int shift, uint32_t tile, uint32_t tile_first, uint32_t (*wcount)[256]) {
+    // wcount[w][d]: pairs with digit d wavefront w has placed so far; later: its first output slot
     const int lane = lane_id(), wave = wave_id();
     for (int i = threadIdx.x; i < 4 * 256; i += 256) (&wcount[0][0])[i] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * (uint32_t)RS_TILE + (uint32_t)wave * (64u * RS_ITEMS);
+    const uint32_t base = tile * (uint32_t)RS_TILE + (uint32_t)wave * (64u * RS_ITEMS);
     uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
@@ -185,9 +185,9 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* __re
     }
     __syncthreads();
     {
-        // thread d: where the tile's digit d starts, and where each wavefront's share of it starts (tile order)
+        // thread d: where each wavefront's share of the tile's digit d starts (tile order)
         const uint32_t d = threadIdx.x;
-        uint32_t run = offs[(size_t)d * n_tiles + blockIdx.x];
+        uint32_t run = tile_first;
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             const uint32_t c = wcount[w][d];
@@ -206,9 +206,74 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* __re
     }
 }
 
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                            uint32_t n, int shift, const uint32_t* __restrict__ offs,
+                                                            uint32_t n_tiles) {
+    __shared__ uint32_t wcount[4][256];
+    radix_scatter_tile(keys_in, vals_in, keys_out, vals_out, n, shift, blockIdx.x, offs[(size_t)threadIdx.x * n_tiles + blockIdx.x], wcount);
+}
+
+// The whole sort in ONE launch when its tiles fit the machine at once (<= one workgroup per CU: 2048 pairs each, i.e. up to
+// ~half a million pairs): the eight dependent steps of the four passes are separated by a grid barrier (an arrival counter
+// polled by one thread per workgroup, as in song_to_song_kernel) instead of by eleven more launches -- at 100 000 pairs a
+// launch costs more than the work it carries.  Every workgroup derives its own offsets from the digit-major table: thread
+// d sums row d (the tiles before its own -> where the tile's share of the digit starts; all tiles -> the digit's total),
+// the totals are scanned over the 256 digits in the workgroup.
+__global__ __launch_bounds__(256) void radix_sort_persistent_kernel(uint32_t* __restrict__ keys_a, uint32_t* __restrict__ vals_a,
+                                                                    uint32_t* __restrict__ keys_b, uint32_t* __restrict__ vals_b,
+                                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                                    uint32_t n, uint32_t* hist, uint32_t* sync) {
+    __shared__ uint32_t wcount[4][256];
+    __shared__ uint32_t h[256];
+    __shared__ uint32_t wsum[4];
+    const uint32_t G = gridDim.x, tile = blockIdx.x, tid = threadIdx.x;
+    uint32_t epoch = 0;
+    auto grid_barrier = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this thread's table entries / pairs are visible to the device
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t target = G * (++epoch);
+            while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    };
+    for (int pass = 0; pass < 4; pass++) {
+        const uint32_t *ki = (pass & 1) ? keys_b : keys_a, *vi = (pass & 1) ? vals_b : vals_a;
+        uint32_t *ko = pass == 3 ? keys_out : ((pass & 1) ? keys_a : keys_b), *vo = pass == 3 ? vals_out : ((pass & 1) ? vals_a : vals_b);
+        const int shift = 8 * pass;
+        h[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; i++) {
+            const uint32_t j = tile * (uint32_t)RS_TILE + (uint32_t)i * 256u + tid;
+            if (j < n) atomicAdd(&h[(ki[j] >> shift) & 0xFFu], 1u);
+        }
+        __syncthreads();
+        hist[(size_t)tid * G + tile] = h[tid];
+        grid_barrier();
+        uint32_t before = 0, total = 0;
+        for (uint32_t t = 0; t < G; t++) {
+            const uint32_t c = hist[(size_t)tid * G + t];
+            before += t < tile ? c : 0u;
+            total += c;
+        }
+        const uint32_t incl = wave_scan_incl_u32(total);
+        if (lane_id() == 63) wsum[wave_id()] = incl;
+        __syncthreads();
+        uint32_t first = incl - total + before;  // pairs with smaller digits + this digit in the tiles before
+        for (int w = 0; w < wave_id(); w++) first += wsum[w];
+        radix_scatter_tile(ki, vi, ko, vo, n, shift, tile, first, wcount);
+        grid_barrier();  // the next pass reads what every tile has written -- and overwrites the table
+    }
+}
+
 // tmp == NULL: report the scratch bytes.  keys_in / vals_in are overwritten (they serve as the second ping-pong buffer).
+// `sync` = one zeroed 32-bit word for the single-launch form, taken when the tiles fit `max_coresident` workgroups.
 hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in,
-                          uint32_t* vals_out, uint32_t n, hipStream_t st) {
+                          uint32_t* vals_out, uint32_t n, hipStream_t st, uint32_t* sync, uint32_t max_coresident) {
     const uint32_t n_tiles = (n + RS_TILE - 1) / RS_TILE;
     const size_t need = ((size_t)2 * n + (size_t)256 * n_tiles + 64) * sizeof(uint32_t);
     if (!tmp) { *tmp_bytes = need; return hipSuccess; }
@@ -217,6 +282,11 @@ hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, uint32_t* keys_in, uint3
     uint32_t* t_keys = reinterpret_cast<uint32_t*>(tmp);
     uint32_t* t_vals = t_keys + n;
     uint32_t* hist = t_vals + n;
+    if (sync && n_tiles <= max_coresident && n_tiles <= 256u) {
+        hipLaunchKernelGGL(radix_sort_persistent_kernel, dim3(n_tiles), dim3(256), 0, st, keys_in, vals_in, t_keys, t_vals, keys_out,
+                           vals_out, n, hist, sync);
+        return hipGetLastError();
+    }
     for (int pass = 0; pass < 4; pass++) {
         const uint32_t *ki = (pass & 1) ? t_keys : keys_in, *vi = (pass & 1) ? t_vals : vals_in;
         uint32_t *ko = pass == 3 ? keys_out : ((pass & 1) ? keys_in : t_keys), *vo = pass == 3 ? vals_out : ((pass & 1) ? vals_in : t_vals);
