@@ -383,3 +383,31 @@ def test_closest_to_songs_sort_is_stable_on_heavy_ties(bliss, n):
     assert np.array_equal(dist, np.abs(x))                       # sqrt(x^2) is exact on these values
     assert np.array_equal(order, np.argsort(np.abs(x), kind="stable"))
     ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BLISSGPU_OPT_TAIL_SPLIT: the tuning estimate + contraction of a one-chunk batch in pieces (a schedule, not an algorithm)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pieces", [2, 3, 8])
+def test_split_tail_gives_the_same_rows(bliss, oracle, pieces):
+    """ragged songs (a too-short one, a two-frame one, a silent one among them) so that the pieces cut at uneven song and
+    tile boundaries; rows and per-song statuses bit-identical to the unsplit schedule, taps of a song in the LAST piece
+    still served"""
+    rng = np.random.default_rng(5)
+    songs = [oracle.white_noise(300 + i, int(n)) for i, n in enumerate(rng.integers(8192, 30 * 22050, 37))]
+    songs[5] = np.zeros(4000, np.float32)
+    songs[9] = oracle.white_noise(399, 8192)
+    songs[20] = np.zeros(5 * 22050, np.float32)
+    ref_ctx = bliss.Context(0)
+    ref, ref_status = _run(ref_ctx, songs, 2)
+    ref_ctx.close()
+    c = bliss.Context(0)
+    c.set_option("tail_split", pieces)
+    c.set_option("debug_chroma", 1)
+    got, status = _run(c, songs, 2)
+    assert c.last_chunks() == 1
+    assert status.tolist() == ref_status.tolist()
+    assert np.array_equal(got, ref, equal_nan=True)
+    shortest = int(np.argmin([len(s) if len(s) >= 8192 else 1 << 30 for s in songs]))   # sorted last: in the last piece
+    assert c.debug_fetch("chroma", shortest).shape[1] == 12 and np.isfinite(c.debug_fetch("interval", shortest)).all()
+    c.close()
