@@ -16,10 +16,11 @@ there is no CPU fallback.
 from ._ffi import BlissGpuError, LIB_PATH  # noqa: F401
 from .song import (  # noqa: F401
     SAMPLE_RATE, CHANNELS, NUMBER_FEATURES, Analysis, AnalysisError, AnalysisIndex, AnalysisIndexv1,
-    AnalysisOptions, BlissError, DecodingError, FeaturesVersion, ProviderError, Song, analyze_batch)
+    AnalysisOptions, BlissError, DecodingError, FeaturesVersion, ProviderError, Song, analyze_batch, analyze_decoded_batch,
+    resampled_len)
 from .decoder import Decoder, PreAnalyzedSong, RawPcmDecoder  # noqa: F401
 from . import playlist  # noqa: F401
 from . import library  # noqa: F401
 from .device import Context, Node  # noqa: F401
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"

@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BLISSGPU_LIB") or os.path.join(_HERE, "libblissgpu.so")
 
 OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_NAN, ERR_RCCL, ERR_TIMEOUT = 0, 1, 2, 3, 4, 5, 6, 7
-SAMPLE_F32, SAMPLE_S16 = 0, 1
+SAMPLE_F32, SAMPLE_S16, SAMPLE_S32 = 0, 1, 2
+SAMPLE_RATE = 22050
 SONG_OK, SONG_TOO_SHORT = 0, 1
 METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_MAHALANOBIS = 0, 1, 2
 OPT_SERIAL, OPT_TAIL_MODE, OPT_PIPELINE_CHUNKS, OPT_CAND_BUDGET, OPT_ROLLOFF_EXACT_ALL, OPT_DEBUG_CHROMA, OPT_TAIL_SPLIT = 0, 1, 2, 3, 4, 5, 6
@@ -24,8 +25,21 @@ _u32p = C.POINTER(C.c_uint32)
 _i32p = C.POINTER(C.c_int32)
 _vp = C.c_void_p
 
+
+
+class DecodedSong(C.Structure):
+    """blissgpu_decoded_song: one song as the decoder delivers it (host memory)."""
+    _fields_ = [("pcm", C.c_void_p), ("frames", C.c_uint64), ("sample_rate", C.c_uint32), ("channels", C.c_uint16),
+                ("sample_format", C.c_uint16)]
+
+
 # name -> (restype, argtypes); must list every symbol include/blissgpu.h declares
 SIGNATURES = {
+    "blissgpu_analyze_decoded": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, _vp, _i32p]),
+    "blissgpu_analyze_batch_decoded": (C.c_int, [C.POINTER(DecodedSong), C.c_uint32, C.c_uint32, _vp, _i32p]),
+    "blissgpu_resampled_len": (C.c_uint64, [C.c_uint64, C.c_uint32]),
+    "blissgpu_resample_filter": (C.c_int, [C.c_uint32, _vp, C.c_uint64, _u32p, _u32p]),
+    "blissgpu_pcm_decode_device": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, _vp]),
     "blissgpu_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "blissgpu_ctx_destroy": (C.c_int, [_vp]),
     "blissgpu_ctx_set_stream": (C.c_int, [_vp, _vp]),
@@ -40,6 +54,7 @@ SIGNATURES = {
     "blissgpu_default_device": (C.c_int, [C.c_int]),
     "blissgpu_default_device_batches": (C.c_uint64, [C.c_int]),
     "blissgpu_set_single_song_timeout_ms": (C.c_int, [C.c_int64]),
+    "blissgpu_default_reset": (C.c_int, []),
     "blissgpu_feature_count": (C.c_uint32, [C.c_uint32]),
     "blissgpu_analyze": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _i32p]),
     "blissgpu_analyze_interleaved": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, _vp, _i32p]),

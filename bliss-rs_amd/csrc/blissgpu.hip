@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <deque>
 #include <mutex>
 #include <string>
@@ -91,12 +92,17 @@ int build_tables(blissgpu_ctx* c) {
 std::mutex g_default_mu;
 std::vector<int> g_default_devices;
 // A default context is created under ITS OWN mutex (building the 40 MB filter bank takes a while: the seats of an 8-GPU node
-// must not queue behind one another, and the counters below must stay readable meanwhile); a creation that failed is
-// remembered -- the seat is retired by the front -- and not retried on every call.
+// must not queue behind one another, and the counters below must stay readable meanwhile).  A creation that failed is
+// remembered and not repeated on every call -- but only a failure that cannot change is remembered for good (no such
+// device, another architecture: BLISSGPU_ERR_NO_DEVICE / _INVALID).  Anything else (no memory for the tables while another
+// process holds the device, a HIP error) is tried again after a back-off that doubles from 100 ms to 5 s, so a long-running
+// host recovers by itself; blissgpu_default_reset() forgets every remembered failure at once.
 struct DefaultSeat {
     std::mutex mu;
     blissgpu_ctx* ctx = nullptr;
-    bool tried = false;
+    int fails = 0;           // consecutive failed creations
+    bool permanent = false;  // the last failure cannot change in this process
+    std::chrono::steady_clock::time_point retry_at{};
     int rc = BLISSGPU_OK;
     std::string err;
 };
@@ -146,17 +152,49 @@ int default_ctx_at(int k, blissgpu_ctx** out) {
         device = g_default_devices[(size_t)k];
     }
     std::lock_guard<std::mutex> lk(seat->mu);
-    if (!seat->tried) {
-        seat->tried = true;
-        seat->rc = blissgpu_ctx_create(device, &seat->ctx);
-        if (seat->rc) {
-            seat->ctx = nullptr;
-            seat->err = std::string("default context ") + std::to_string(k) + " (HIP device " + std::to_string(device) + "): " + blissgpu_last_error();
+    if (!seat->ctx) {
+        const auto now = std::chrono::steady_clock::now();
+        if (seat->fails == 0 || (!seat->permanent && now >= seat->retry_at)) {
+            seat->rc = blissgpu_ctx_create(device, &seat->ctx);
+            if (seat->rc) {
+                seat->ctx = nullptr;
+                seat->fails++;
+                seat->permanent = seat->rc == BLISSGPU_ERR_NO_DEVICE || seat->rc == BLISSGPU_ERR_INVALID;
+                seat->retry_at = now + std::chrono::milliseconds(std::min(5000, 100 << std::min(seat->fails - 1, 6)));
+                seat->err = std::string("default context ") + std::to_string(k) + " (HIP device " + std::to_string(device) + "): " + blissgpu_last_error();
+            } else {
+                seat->fails = 0;
+                seat->permanent = false;
+            }
         }
     }
-    if (seat->rc) return fail(seat->rc, "default context", seat->err.c_str());
+    if (!seat->ctx) return fail(seat->rc, "default context", seat->err.c_str());
     *out = seat->ctx;
     return BLISSGPU_OK;
+}
+void default_ctx_forget_failures() {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    default_init_locked();
+    for (DefaultSeat& seat : g_default_seats) {
+        std::lock_guard<std::mutex> sl(seat.mu);
+        if (!seat.ctx) { seat.fails = 0; seat.permanent = false; seat.rc = BLISSGPU_OK; }
+    }
+}
+// live contexts per HIP device in this process (the single-launch sort and the song_to_song chain spin on grid barriers:
+// they assume their workgroups are co-resident, which holds with margin for two contexts' worth of them on a device)
+namespace {
+std::mutex g_live_mu;
+std::vector<int> g_live_contexts;
+}
+void live_context_add(int device, int delta) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    if (device < 0) return;
+    if ((size_t)device >= g_live_contexts.size()) g_live_contexts.resize((size_t)device + 1, 0);
+    g_live_contexts[(size_t)device] += delta;
+}
+int live_contexts(int device) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    return device >= 0 && (size_t)device < g_live_contexts.size() ? g_live_contexts[(size_t)device] : 0;
 }
 int64_t single_song_timeout_ms() { return g_single_song_timeout_ms.load(); }
 int default_ctx(blissgpu_ctx** out) { return default_ctx_at(0, out); }
@@ -169,7 +207,14 @@ void default_ctx_count_batch(int k) {
 extern "C" {
 int blissgpu_default_device_count(void) { return default_ctx_count(); }
 int blissgpu_set_single_song_timeout_ms(int64_t ms) {
-    g_single_song_timeout_ms.store(ms > 0 ? ms : 600000);
+    // "never" (INT64_MAX) must not overflow the nanosecond clock the deadline is computed on: ten years is never
+    constexpr int64_t TEN_YEARS_MS = 10LL * 365 * 24 * 3600 * 1000;
+    g_single_song_timeout_ms.store(ms > 0 ? std::min(ms, TEN_YEARS_MS) : 600000);
+    return BLISSGPU_OK;
+}
+int blissgpu_default_reset(void) {
+    default_ctx_forget_failures();
+    front_revive_all();
     return BLISSGPU_OK;
 }
 int blissgpu_default_device(int k) {
@@ -202,7 +247,7 @@ int is_diag(const float* M, uint32_t d) {
 
 extern "C" {
 
-const char* blissgpu_version(void) { return "blissgpu 0.2.0 (gfx950)"; }
+const char* blissgpu_version(void) { return "blissgpu 0.3.0 (gfx950)"; }
 const char* blissgpu_last_error(void) { return g_last_error.c_str(); }
 
 const char* blissgpu_strerror(int code) {
@@ -254,12 +299,15 @@ int blissgpu_ctx_create(int device, blissgpu_ctx** out) {
         c->ws_limit = 16ull << 30;
     int rc = build_tables(c);
     if (rc) { blissgpu_ctx_destroy(c); return rc; }
+    live_context_add(device, 1);
+    c->counted_live = true;
     *out = c;
     return BLISSGPU_OK;
 }
 
 int blissgpu_ctx_destroy(blissgpu_ctx* c) {
     if (!c) return BLISSGPU_OK;
+    if (c->counted_live) live_context_add(c->device, -1);
     {
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         (void)hipSetDevice(c->device);
@@ -536,8 +584,10 @@ int blissgpu_closest_to_songs_device(blissgpu_ctx* c, const float* d_seeds, uint
         launch_set_distance(d_seeds, n_seeds, d_cand, n, d, metric, d_M, d_dist, keys_in, idx_in, c->pl_sync.p + 1, c->stream);
     }
     HIP_TRY(hipGetLastError());
+    // the single-launch sort spins on grid barriers: only while its workgroups are certainly co-resident (one per CU, and at
+    // most two contexts' worth of persistent kernels on the device); otherwise one launch per step
     HIP_TRY(sort_pairs_u32(c->pl_tmp.p, &tmp_bytes, keys_in, keys_out, idx_in, d_order, n32, c->stream, c->pl_sync.p + 2,
-                           (uint32_t)std::max(1, c->n_cus)));
+                           live_contexts(c->device) <= 2 ? (uint32_t)std::max(1, c->n_cus) : 0u));
     return nan_check(c, c->pl_sync.p + 1, "blissgpu_closest_to_songs_device");
 }
 

@@ -11,7 +11,9 @@
 //
 // A seat whose runner reports it unusable (its device cannot give a context: busy, full, another architecture, a bad
 // ordinal) is RETIRED: the batch goes back to the head of the queue for another seat, and the seat draws no more traffic.
-// Only when every seat is retired do requests fail (NO_SEAT).
+// Only when every seat is retired do requests fail (NO_SEAT).  Retirement is not for ever: a retired seat is offered one
+// more batch after a rest that doubles from revive_base (1 s) to 64 x that -- the runner decides again whether the seat is
+// usable (a device that was full when the process started may have room now) -- and revive_all() ends every rest at once.
 //
 // No caller blocks forever on the front's own account: a request that no leader has picked up by its deadline is withdrawn
 // and fails with TIMED_OUT (describe() names the seats and the queue).  A request a leader HAS picked up is waited for
@@ -45,7 +47,12 @@ class CoalescingFront {
     template <typename Run>
     FrontOutcome submit(Req& r, int n_seats, Run&& run, std::chrono::milliseconds deadline = std::chrono::minutes(10)) {
         std::unique_lock<std::mutex> lk(mu_);
-        if (seat_.empty()) { seat_.assign((size_t)n_seats, SEAT_FREE); seat_last_batch_.assign((size_t)n_seats, 1); }
+        if (seat_.empty()) {
+            seat_.assign((size_t)n_seats, SEAT_FREE);
+            seat_last_batch_.assign((size_t)n_seats, 1);
+            seat_retired_until_.assign((size_t)n_seats, std::chrono::steady_clock::time_point{});
+            seat_retirements_.assign((size_t)n_seats, 0);
+        }
         const auto t_end = std::chrono::steady_clock::now() + deadline;
         queue_.push_back(&r);
         cv_arrive_.notify_one();
@@ -68,6 +75,11 @@ class CoalescingFront {
         };
         while (!r.done) {
             int seat = -1, alive = 0;
+            {
+                const auto now = std::chrono::steady_clock::now();
+                for (int k = 0; k < n_seats; k++)  // a retired seat whose rest is over gets one more try
+                    if (seat_[(size_t)k] == SEAT_RETIRED && now >= seat_retired_until_[(size_t)k]) seat_[(size_t)k] = SEAT_FREE;
+            }
             for (int k = 0; k < n_seats; k++) {
                 if (seat_[(size_t)k] != SEAT_RETIRED) alive++;
                 if (seat < 0 && seat_[(size_t)k] == SEAT_FREE) seat = k;
@@ -116,9 +128,13 @@ class CoalescingFront {
             if (dealt_with) {
                 for (Req* t : take) t->done = true;
                 seat_[(size_t)seat] = SEAT_FREE;
+                seat_retirements_[(size_t)seat] = 0;
             } else {
                 seat_[(size_t)seat] = SEAT_RETIRED;
                 seat_last_batch_[(size_t)seat] = 1;
+                seat_retired_until_[(size_t)seat] =
+                    std::chrono::steady_clock::now() + revive_base_ * (1 << std::min(seat_retirements_[(size_t)seat], 6));
+                seat_retirements_[(size_t)seat]++;
                 bool any = false;
                 for (char s : seat_) any = any || s != SEAT_RETIRED;
                 if (any) {
@@ -146,6 +162,19 @@ class CoalescingFront {
         return s + "], " + std::to_string(queue_.size()) + " request(s) queued";
     }
 
+    // every retired seat is offered traffic again (the runner decides anew whether it is usable)
+    void revive_all() {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (size_t k = 0; k < seat_.size(); k++)
+            if (seat_[k] == SEAT_RETIRED) { seat_[k] = SEAT_FREE; seat_retirements_[k] = 0; }
+        cv_done_.notify_all();
+    }
+    // the first rest of a retired seat (doubles with every further retirement, up to 64 x)
+    void set_revive_base(std::chrono::milliseconds base) {
+        std::lock_guard<std::mutex> lk(mu_);
+        revive_base_ = base;
+    }
+
     int retired_seats() {
         std::lock_guard<std::mutex> lk(mu_);
         int n = 0;
@@ -160,6 +189,9 @@ class CoalescingFront {
     std::vector<Req*> queue_;
     std::vector<char> seat_;
     std::vector<size_t> seat_last_batch_;
+    std::vector<std::chrono::steady_clock::time_point> seat_retired_until_;
+    std::vector<int> seat_retirements_;  // consecutive retirements of the seat
+    std::chrono::milliseconds revive_base_{1000};
 };
 
 }  // namespace bg

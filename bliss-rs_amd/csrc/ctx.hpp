@@ -6,12 +6,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/blissgpu.h"
 #include "internal.hpp"
+#include "resample.hpp"
 
 namespace bg {
 
@@ -98,6 +100,23 @@ struct ChunkSlot {
 #define FEED_COPY_STREAMS 2
 #endif
 constexpr int N_COPY_STREAMS = FEED_COPY_STREAMS;
+// one song of the host PCM feed as the decoder delivers it
+constexpr uint32_t MAX_SAMPLE_RATE = 768000;  // the resample kernel's 64-bit stream positions hold for any song below this
+struct FeedSong {
+    const void* p;      // host memory
+    uint64_t frames;    // of `channels` interleaved samples
+    uint32_t rate;      // Hz; anything but 22 050 goes through the device resampler
+    uint8_t fmt;        // BLISSGPU_SAMPLE_*
+    uint8_t channels;   // 1..8
+    size_t frame_bytes() const { return (size_t)(fmt == BLISSGPU_SAMPLE_S16 ? 2 : 4) * channels; }
+    bool direct() const { return fmt == BLISSGPU_SAMPLE_F32 && channels == 1 && rate == SWR_OUT_RATE; }  // copied verbatim
+};
+// the device resampler's filter bank for one input rate
+struct ResampleBank {
+    SwrPlan plan;
+    float* d_bank = nullptr;
+};
+
 struct HostFeed {
     DevBuf<float> pcm[2];
     DevBuf<uint8_t> raw[2];
@@ -126,6 +145,7 @@ struct blissgpu_ctx {
     int tail_split = 0;                // BLISSGPU_OPT_TAIL_SPLIT: one-chunk batches run the tuning estimate + contraction in two halves
     bool debug_chroma = false;         // BLISSGPU_OPT_DEBUG_CHROMA (tests): keep the chroma matrix / interval means of the last chunk
     bool serial = false;               // BLISSGPU_OPT_SERIAL: single stream (clean per-kernel timings)
+    bool counted_live = false;         // this context is in the per-device count of live contexts
     uint64_t ws_limit = 0;             // bytes per chunk slot (set from the free device memory at creation)
     uint32_t cand_budget = bg::CAND_BUDGET_PER_FRAME;  // tuning-candidate pool: slots per chroma frame of a chunk
     // tables
@@ -144,6 +164,7 @@ struct blissgpu_ctx {
     std::vector<bg::SongDesc> last_songs;    // its descriptors (chunk order; SongDesc::row = the caller's song index)
     uint64_t last_chunks = 0;                // chunks of the last analyze call
     bg::HostFeed feed;
+    std::map<uint32_t, bg::ResampleBank> swr_banks;  // filter banks of the input rates seen so far (guarded by mu)
     // distances / playlist ordering scratch
     int n_cus = 0;
     bg::DevBuf<uint32_t> pl_sync, pl_keys;
@@ -191,14 +212,23 @@ int default_ctx_at(int k, blissgpu_ctx** out);
 int default_ctx(blissgpu_ctx** out);  // = default_ctx_at(0): the batch / distance / playlist forms without a context argument
 void default_ctx_count_batch(int k);  // statistics: one more coalesced batch served by default context k
 int64_t single_song_timeout_ms();     // blissgpu_set_single_song_timeout_ms
+void default_ctx_forget_failures();   // blissgpu_default_reset: remembered creation failures are forgotten
+void front_revive_all();              // ... and the front's retired seats draw traffic again (scheduler.hip)
+int live_contexts(int device);        // contexts alive on a HIP device in this process
 
 // scheduler.hip
 void scheduler_release(blissgpu_ctx* c);
-// Host PCM feed: song i = ptrs[i] (host memory), lengths[i] FRAMES of `channels` interleaved samples of
-// `bytes_per_sample` (4: f32, 2: s16); channels > 1 are downmixed on the device.
+// Host PCM feed: decoder output in host memory, song by song (any mix of formats, channel counts and sample rates); widening,
+// downmix and resampling happen on the device.
 // d_rows (device, n_songs x feature_count, may be NULL) receives a copy of the rows that stays on the device.
-int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t* lengths, uint32_t n_songs,
-                       int bytes_per_sample, uint32_t channels, uint32_t features_version, float* out, int32_t* status,
-                       const char* who, float* d_rows = nullptr);
+int analyze_host_songs(blissgpu_ctx* c, const FeedSong* songs, uint32_t n_songs, uint32_t features_version, float* out,
+                       int32_t* status, const char* who, float* d_rows = nullptr);
+// the uniform form: song i = ptrs[i], lengths[i] FRAMES of `channels` interleaved samples of `sample_format`
+int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t* lengths, uint32_t n_songs, int sample_format,
+                       uint32_t channels, uint32_t features_version, float* out, int32_t* status, const char* who,
+                       float* d_rows = nullptr, uint32_t sample_rate = SWR_OUT_RATE);
+int resample_bank(blissgpu_ctx* c, uint32_t rate, const ResampleBank** out, const char* who);
+int enqueue_decode(blissgpu_ctx* c, const void* d_in, int fmt, uint32_t channels, uint64_t frames, uint32_t rate, float* d_out,
+                   uint64_t n_out, hipStream_t st, const char* who);
 
 }  // namespace bg

@@ -192,8 +192,13 @@ void launch_summary(const Batch&, const Workspace&, hipStream_t);
 void launch_finalize(const Batch&, const Workspace&, uint32_t features_version, float* d_out, int32_t* d_status,
                      int32_t* dbg_tuning, uint32_t* dbg_nbpms, hipStream_t);
 void launch_chroma_bank(double* bank, hipStream_t);
-// raw decoder output -> mono f32: bytes_per_sample 2 (s16, sample / 32768) or 4 (f32), `channels` interleaved
-void launch_pcm_convert(const void* in, int bytes_per_sample, uint32_t channels, float* out, uint64_t frames, hipStream_t st);
+// raw decoder output at 22 050 Hz -> mono f32: sample_format BLISSGPU_SAMPLE_* (s16: sample / 32768, s32: sample / 2^31),
+// `channels` interleaved
+void launch_pcm_convert(const void* in, int sample_format, uint32_t channels, float* out, uint64_t frames, hipStream_t st);
+// raw decoder output at another rate -> mono 22 050 Hz f32 (libswresample's default resampler, resample.hpp)
+struct SwrPlan;
+hipError_t launch_resample(const void* in, int sample_format, uint32_t channels, uint64_t frames, const SwrPlan& plan,
+                           const float* d_bank, float* out, uint64_t n_out, hipStream_t st);
 // one pair distance with both vectors passed by value (no staging copies); result -> *out (device-visible host word)
 void launch_pair_distance(const float* a, const float* b, uint32_t d, int metric, const float* d_M, float* out, hipStream_t st);
 // playlist ordering (kernels_playlist.hip)

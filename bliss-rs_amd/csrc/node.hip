@@ -350,7 +350,7 @@ int blissgpu_node_analyze(blissgpu_node* nd, const float* pcm, const uint64_t* o
             for (size_t j = 0; j < mine.size(); j++) { ptrs[j] = pcm + offsets[mine[j]]; lens[j] = lengths[mine[j]]; }
             rows[r].resize(mine.size() * (size_t)d);
             // the rows go to the host (the caller's `out`) AND stay on the device in send[r] for the gather
-            rcs[r] = analyze_host_songs(nd->ctx[r], ptrs.data(), lens.data(), (uint32_t)mine.size(), 4, 1, features_version,
+            rcs[r] = analyze_host_songs(nd->ctx[r], ptrs.data(), lens.data(), (uint32_t)mine.size(), BLISSGPU_SAMPLE_F32, 1, features_version,
                                         rows[r].data(), nullptr, "blissgpu_node_analyze", nd->send[r].p);
             if (rcs[r]) errs[r] = blissgpu_last_error();
         });

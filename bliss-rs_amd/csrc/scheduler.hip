@@ -339,6 +339,9 @@ void scheduler_release(blissgpu_ctx* c) {
         s = ChunkSlot{};
     }
     HostFeed& f = c->feed;
+    for (auto& kv : c->swr_banks)
+        if (kv.second.d_bank) (void)hipFree(kv.second.d_bank);
+    c->swr_banks.clear();
     for (hipStream_t& cs : f.copy_stream)
         if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); cs = nullptr; }
     for (int b = 0; b < 2; b++) {
@@ -361,13 +364,65 @@ void scheduler_release(blissgpu_ctx* c) {
 #ifndef FEED_GROUP_MIB
 #define FEED_GROUP_MIB 512
 #endif
-int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t* lengths, uint32_t n_songs,
-                       int bytes_per_sample, uint32_t channels, uint32_t features_version, float* out, int32_t* status,
-                       const char* who, float* d_rows) {
+// the filter bank of one input rate, built once per context (resample.hpp) and kept on the device
+int resample_bank(blissgpu_ctx* c, uint32_t rate, const ResampleBank** out, const char* who) {
+    auto it = c->swr_banks.find(rate);
+    if (it == c->swr_banks.end()) {
+        ResampleBank rb;
+        if (rate > MAX_SAMPLE_RATE || !swr_make_plan(rate, &rb.plan))
+            return fail(BLISSGPU_ERR_INVALID, who, "sample_rate must be 1 .. 768000 Hz");
+        std::vector<float> bank;
+        swr_make_filter(rb.plan, bank);
+        float* d = nullptr;
+        hipError_t e = hipMalloc((void**)&d, bank.size() * sizeof(float));
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(BLISSGPU_ERR_OOM, "hipMalloc(resample bank)", hipGetErrorString(e)); }
+        e = hipMemcpy(d, bank.data(), bank.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); return fail(BLISSGPU_ERR_HIP, "hipMemcpy(resample bank)", hipGetErrorString(e)); }
+        rb.d_bank = d;
+        it = c->swr_banks.emplace(rate, rb).first;
+    }
+    *out = &it->second;
+    return BLISSGPU_OK;
+}
+
+// decoder output of one song (device) -> mono 22 050 Hz f32 (device), on `st`
+int enqueue_decode(blissgpu_ctx* c, const void* d_in, int fmt, uint32_t channels, uint64_t frames, uint32_t rate, float* d_out,
+                   uint64_t n_out, hipStream_t st, const char* who) {
+    if (rate == SWR_OUT_RATE) {
+        launch_pcm_convert(d_in, fmt, channels, d_out, frames, st);
+        HIP_TRY(hipGetLastError());
+        return BLISSGPU_OK;
+    }
+    const ResampleBank* rb;
+    const int rc = resample_bank(c, rate, &rb, who);
+    if (rc) return rc;
+    HIP_TRY(launch_resample(d_in, fmt, channels, frames, rb->plan, rb->d_bank, d_out, n_out, st));
+    return BLISSGPU_OK;
+}
+
+int analyze_host_songs(blissgpu_ctx* c, const FeedSong* in, uint32_t n_songs, uint32_t features_version, float* out,
+                       int32_t* status, const char* who, float* d_rows) {
     const uint32_t d = blissgpu_feature_count(features_version);
     if (!d) return fail(BLISSGPU_ERR_INVALID, who, "features_version must be 1 or 2");
-    if (channels == 0 || channels > 8) return fail(BLISSGPU_ERR_INVALID, who, "channels must be 1..8");
     if (n_songs == 0) return BLISSGPU_OK;
+    // what every song becomes: its mono 22 050 Hz length, and whether it needs the device conversion at all
+    std::vector<uint64_t> out_len(n_songs);
+    bool any_raw = false;
+    for (uint32_t i = 0; i < n_songs; i++) {
+        const FeedSong& fs = in[i];
+        if (fs.channels == 0 || fs.channels > 8) return fail(BLISSGPU_ERR_INVALID, who, "channels must be 1..8");
+        if (fs.fmt != BLISSGPU_SAMPLE_F32 && fs.fmt != BLISSGPU_SAMPLE_S16 && fs.fmt != BLISSGPU_SAMPLE_S32)
+            return fail(BLISSGPU_ERR_INVALID, who, "sample_format must be F32, S16 or S32");
+        if (fs.rate == 0 || fs.rate > MAX_SAMPLE_RATE) return fail(BLISSGPU_ERR_INVALID, who, "sample_rate must be 1 .. 768000 Hz");
+        if (fs.frames && !fs.p) return fail(BLISSGPU_ERR_INVALID, who, "NULL song pointer");
+        if (fs.rate == SWR_OUT_RATE) out_len[i] = fs.frames;
+        else {
+            SwrPlan pl;
+            swr_make_plan(fs.rate, &pl);
+            out_len[i] = swr_out_len(pl, fs.frames);
+        }
+        any_raw = any_raw || !fs.direct();
+    }
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     HostFeed& f = c->feed;
@@ -380,36 +435,43 @@ int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t*
             if (!f.ev_done[b]) HIP_TRY(hipEventCreateWithFlags(&f.ev_done[b], hipEventDisableTiming));
         }
     }
-    const bool direct = bytes_per_sample == 4 && channels == 1;  // f32 mono: copied verbatim into the PCM buffer
-    const size_t frame_bytes = (size_t)bytes_per_sample * channels;
     // groups of <= 512 MiB of staging (mono f32: ~32 three-minute songs).  The transfer is the bottleneck (a group's
     // analysis takes a tenth of its transfer time), so what a call pays beyond its bytes is the analysis of the LAST group:
     // small groups keep that tail short, and 32 songs still fill the GPU several times over.  The cap is in BYTES of the
-    // wider of the two buffers of a group (raw interleaved frames / mono f32), so an 8-channel f32 batch stages
+    // wider of the two buffers of a group (raw decoder output / mono f32), so an 8-channel f32 batch stages
     // 2 x 512 MiB like a mono one instead of 2 x 4 GiB.
-    const uint64_t group_cap = ((uint64_t)FEED_GROUP_MIB << 20) / std::max<size_t>(4, frame_bytes);  // frames
-    struct Group { uint32_t i0, n; std::vector<uint64_t> doff, dlen; uint64_t total; };
+    const uint64_t group_cap = (uint64_t)FEED_GROUP_MIB << 20;  // bytes
+    struct Group { uint32_t i0, n; std::vector<uint64_t> doff, dlen, roff; uint64_t total, raw_total; };
     std::vector<Group> groups;
     for (uint32_t i0 = 0; i0 < n_songs;) {
-        Group g{i0, 0, {}, {}, 0};
+        Group g{i0, 0, {}, {}, {}, 0, 0};
         uint32_t i1 = i0;
-        while (i1 < n_songs && (i1 == i0 || g.total + lengths[i1] <= group_cap)) {
+        while (i1 < n_songs) {
+            const uint64_t raw = in[i1].direct() ? 0 : (in[i1].frames + 63) / 64 * 64 * in[i1].frame_bytes();  // padded like the PCM
+            const uint64_t pcm = (out_len[i1] + 63) / 64 * 64;
+            if (i1 > i0 && (4 * (g.total + pcm) > group_cap || g.raw_total + raw > group_cap)) break;
             g.doff.push_back(g.total);
-            g.dlen.push_back(lengths[i1]);
-            g.total += (lengths[i1] + 63) / 64 * 64;
+            g.dlen.push_back(out_len[i1]);
+            g.roff.push_back(g.raw_total);
+            g.total += pcm;
+            g.raw_total += raw;
             i1++;
         }
         g.n = i1 - i0;
         groups.push_back(std::move(g));
         i0 = i1;
     }
-    uint64_t max_total = 64, max_n = 1;
-    for (const auto& g : groups) { max_total = std::max(max_total, g.total); max_n = std::max<uint64_t>(max_n, g.n); }
+    uint64_t max_total = 64, max_raw = 0, max_n = 1;
+    for (const auto& g : groups) {
+        max_total = std::max(max_total, g.total);
+        max_raw = std::max(max_raw, g.raw_total);
+        max_n = std::max<uint64_t>(max_n, g.n);
+    }
     const int nbuf = groups.size() > 1 ? 2 : 1;
     int rc = BLISSGPU_OK;
     for (int b = 0; b < nbuf && !rc; b++) {
         rc = f.pcm[b].ensure(max_total);
-        if (!rc && !direct) rc = f.raw[b].ensure(max_total * frame_bytes);
+        if (!rc && any_raw) rc = f.raw[b].ensure(max_raw + 256);
         if (!rc) rc = f.out[b].ensure(max_n * d);
     }
     if (rc) return rc;
@@ -422,12 +484,14 @@ int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t*
         hipError_t ee = hipSuccess;
         for (int q = 0; q < N_COPY_STREAMS && ee == hipSuccess && gi >= (size_t)nbuf; q++)
             ee = hipStreamWaitEvent(f.copy_stream[q], f.ev_done[b], 0);
-        for (uint32_t k = 0; k < g.n && ee == hipSuccess; k++)
-            if (g.dlen[k]) {
-                void* dst = direct ? (void*)(f.pcm[b].p + g.doff[k]) : (void*)(f.raw[b].p + g.doff[k] * frame_bytes);
-                ee = hipMemcpyAsync(dst, ptrs[g.i0 + k], g.dlen[k] * frame_bytes, hipMemcpyHostToDevice,
+        for (uint32_t k = 0; k < g.n && ee == hipSuccess; k++) {
+            const FeedSong& fs = in[g.i0 + k];
+            if (fs.frames) {
+                void* dst = fs.direct() ? (void*)(f.pcm[b].p + g.doff[k]) : (void*)(f.raw[b].p + g.roff[k]);
+                ee = hipMemcpyAsync(dst, fs.p, fs.frames * fs.frame_bytes(), hipMemcpyHostToDevice,
                                     f.copy_stream[k % N_COPY_STREAMS]);
             }
+        }
         for (int q = 0; q < N_COPY_STREAMS && ee == hipSuccess; q++) ee = hipEventRecord(f.ev_copied[b][q], f.copy_stream[q]);
         return ee;
     };
@@ -442,11 +506,27 @@ int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t*
         if (gi + 1 < groups.size()) e = upload(gi + 1);
         for (int q = 0; q < N_COPY_STREAMS && e == hipSuccess; q++) e = hipStreamWaitEvent(c->stream, f.ev_copied[b][q], 0);
         if (e != hipSuccess) break;
-        if (!direct) {
-            launch_pcm_convert(f.raw[b].p, bytes_per_sample, channels, f.pcm[b].p, g.total, c->stream);
-            e = hipGetLastError();
-            if (e != hipSuccess) break;
+        // widening / downmix / resampling on the device.  A group of one format at 22 050 Hz (the bulk case: s16 from the
+        // decoder) is ONE launch over the whole staging area -- its songs are packed with the same 64-frame padding in both
+        // buffers; anything else goes song by song (a launch per song is nothing beside the song's transfer)
+        bool uniform = true;
+        for (uint32_t k = 0; k < g.n && uniform; k++) {
+            const FeedSong &a0 = in[g.i0], &ak = in[g.i0 + k];
+            uniform = !ak.direct() && ak.rate == SWR_OUT_RATE && ak.fmt == a0.fmt && ak.channels == a0.channels &&
+                      g.roff[k] == g.doff[k] * ak.frame_bytes();
         }
+        if (uniform) {
+            launch_pcm_convert(f.raw[b].p, in[g.i0].fmt, in[g.i0].channels, f.pcm[b].p, g.total, c->stream);
+            e = hipGetLastError();
+        } else {
+            for (uint32_t k = 0; k < g.n && !rc; k++) {
+                const FeedSong& fs = in[g.i0 + k];
+                if (fs.direct() || fs.frames == 0) continue;
+                rc = enqueue_decode(c, f.raw[b].p + g.roff[k], fs.fmt, fs.channels, fs.frames, fs.rate, f.pcm[b].p + g.doff[k],
+                                    g.dlen[k], c->stream, who);
+            }
+        }
+        if (e != hipSuccess || rc) break;
         rc = blissgpu_analyze_batch_device(c, f.pcm[b].p, g.doff.data(), g.dlen.data(), g.n, features_version, f.out[b].p, nullptr);
         if (rc) break;
         e = hipMemcpyAsync(out + (size_t)g.i0 * d, f.out[b].p, (size_t)g.n * d * sizeof(float), hipMemcpyDeviceToHost, c->stream);
@@ -470,6 +550,16 @@ int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t*
     return BLISSGPU_OK;
 }
 
+// the uniform form (every song one format, channel count and rate)
+int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t* lengths, uint32_t n_songs, int sample_format,
+                       uint32_t channels, uint32_t features_version, float* out, int32_t* status, const char* who,
+                       float* d_rows, uint32_t sample_rate) {
+    std::vector<FeedSong> songs(n_songs);
+    for (uint32_t i = 0; i < n_songs; i++)
+        songs[i] = FeedSong{ptrs[i], lengths[i], sample_rate, (uint8_t)sample_format, (uint8_t)(channels > 255 ? 255 : channels)};
+    return analyze_host_songs(c, songs.data(), n_songs, features_version, out, status, who, d_rows);
+}
+
 }  // namespace bg
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -484,8 +574,8 @@ namespace {
 struct AnalyzeReq {
     const void* pcm;
     uint64_t frames;
-    int bytes_per_sample;
-    uint32_t channels, version;
+    int sample_format;
+    uint32_t channels, sample_rate, version;
     float* out;
     int32_t status = BLISSGPU_SONG_OK;
     int rc = BLISSGPU_OK;
@@ -520,25 +610,26 @@ bool run_batch(std::vector<AnalyzeReq*>& take, int seat, const char* who) {
         g_seat_err = blissgpu_last_error();
         return false;
     }
-    // one device batch per (sample format, channels, features version) class; in practice there is one class
+    // one device batch per features version (the songs of a batch may differ in format, channel count and rate; in practice
+    // there is one version)
     std::vector<char> served(take.size(), 0);
     for (size_t a = 0; a < take.size(); a++) {
         if (served[a]) continue;
         std::vector<size_t> cls;
         for (size_t q = a; q < take.size(); q++)
-            if (!served[q] && take[q]->bytes_per_sample == take[a]->bytes_per_sample &&
-                take[q]->channels == take[a]->channels && take[q]->version == take[a]->version) {
+            if (!served[q] && take[q]->version == take[a]->version) {
                 cls.push_back(q);
                 served[q] = 1;
             }
         const uint32_t d = blissgpu_feature_count(take[a]->version);
-        std::vector<const void*> ptrs(cls.size());
-        std::vector<uint64_t> lens(cls.size());
+        std::vector<bg::FeedSong> songs(cls.size());
         std::vector<int32_t> st(cls.size(), 0);
         std::vector<float> rows(cls.size() * (size_t)std::max(d, 1u));
-        for (size_t q = 0; q < cls.size(); q++) { ptrs[q] = take[cls[q]]->pcm; lens[q] = take[cls[q]]->frames; }
-        const int rc = analyze_host_songs(c, ptrs.data(), lens.data(), (uint32_t)cls.size(), take[a]->bytes_per_sample,
-                                          take[a]->channels, take[a]->version, rows.data(), st.data(), who);
+        for (size_t q = 0; q < cls.size(); q++) {
+            const AnalyzeReq* t = take[cls[q]];
+            songs[q] = bg::FeedSong{t->pcm, t->frames, t->sample_rate, (uint8_t)t->sample_format, (uint8_t)t->channels};
+        }
+        const int rc = analyze_host_songs(c, songs.data(), (uint32_t)cls.size(), take[a]->version, rows.data(), st.data(), who);
         const std::string err = rc ? blissgpu_last_error() : "";
         for (size_t q = 0; q < cls.size(); q++) {
             AnalyzeReq* t = take[cls[q]];
@@ -577,21 +668,27 @@ int submit(AnalyzeReq& r, const char* who) {
     return BLISSGPU_OK;
 }
 
-int analyze_one(const void* pcm, uint64_t frames, int bytes, uint32_t channels, uint32_t version, float* out,
-                int32_t* status, const char* who) {
+bool known_format(int sample_format) {
+    return sample_format == BLISSGPU_SAMPLE_F32 || sample_format == BLISSGPU_SAMPLE_S16 || sample_format == BLISSGPU_SAMPLE_S32;
+}
+
+int analyze_one(const void* pcm, uint64_t frames, int sample_format, uint32_t channels, uint32_t sample_rate, uint32_t version,
+                float* out, int32_t* status, const char* who) {
     if (!out || (frames && !pcm)) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
     if (!blissgpu_feature_count(version)) return fail(BLISSGPU_ERR_INVALID, who, "features_version must be 1 or 2");
     if (channels == 0 || channels > 8) return fail(BLISSGPU_ERR_INVALID, who, "channels must be 1..8");
-    AnalyzeReq r{pcm, frames, bytes, channels, version, out};
+    if (sample_rate == 0 || sample_rate > bg::MAX_SAMPLE_RATE) return fail(BLISSGPU_ERR_INVALID, who, "sample_rate must be 1 .. 768000 Hz");
+    AnalyzeReq r{pcm, frames, sample_format, channels, sample_rate, version, out};
     const int rc = submit(r, who);
     if (status) *status = r.status;
     return rc;
 }
 
 int batch_from_offsets(const void* pcm, size_t frame_bytes, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
-                       int bytes, uint32_t channels, uint32_t version, float* out, int32_t* status, const char* who) {
+                       int sample_format, uint32_t channels, uint32_t version, float* out, int32_t* status, const char* who) {
     if (n_songs && (!pcm || !offsets || !lengths || !out)) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
     if (!blissgpu_feature_count(version)) return fail(BLISSGPU_ERR_INVALID, who, "features_version must be 1 or 2");
+    if (channels == 0 || channels > 8) return fail(BLISSGPU_ERR_INVALID, who, "channels must be 1..8");
     if (n_songs == 0) return BLISSGPU_OK;
     DeviceRestore restore;
     blissgpu_ctx* c;
@@ -599,10 +696,14 @@ int batch_from_offsets(const void* pcm, size_t frame_bytes, const uint64_t* offs
     if (rc) return rc;
     std::vector<const void*> ptrs(n_songs);
     for (uint32_t i = 0; i < n_songs; i++) ptrs[i] = (const uint8_t*)pcm + offsets[i] * frame_bytes;
-    return analyze_host_songs(c, ptrs.data(), lengths, n_songs, bytes, channels, version, out, status, who);
+    return analyze_host_songs(c, ptrs.data(), lengths, n_songs, sample_format, channels, version, out, status, who);
 }
 
 }  // namespace
+
+namespace bg {
+void front_revive_all() { g_front.revive_all(); }
+}  // namespace bg
 
 extern "C" {
 
@@ -654,6 +755,11 @@ int blissgpu_analyze_batch_device(blissgpu_ctx* c, const float* d_pcm, const uin
         }
         todo.push_back({b0, n_songs});
     }
+    // the chroma / interval taps are ONE buffer per context, sized per chunk: a second chunk's front half would resize it
+    // under the first chunk's back half
+    if (c->debug_chroma && todo.size() > 1)
+        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_batch_device",
+                    "BLISSGPU_OPT_DEBUG_CHROMA needs a batch that fits one chunk (raise the workspace limit or analyse fewer songs)");
     std::reverse(todo.begin(), todo.end());  // used as a stack
     uint64_t chunks = 0;
     ChunkSlot* prev = nullptr;  // the chunk whose back half is still to be enqueued
@@ -691,42 +797,71 @@ int blissgpu_analyze_batch_device(blissgpu_ctx* c, const float* d_pcm, const uin
 
 int blissgpu_analyze_batch(const float* pcm, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
                            uint32_t features_version, float* out, int32_t* status) {
-    return batch_from_offsets(pcm, 4, offsets, lengths, n_songs, 4, 1, features_version, out, status, "blissgpu_analyze_batch");
+    return batch_from_offsets(pcm, 4, offsets, lengths, n_songs, BLISSGPU_SAMPLE_F32, 1, features_version, out, status,
+                              "blissgpu_analyze_batch");
 }
 
 int blissgpu_analyze_batch_s16(const int16_t* pcm, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_songs,
                                uint32_t features_version, float* out, int32_t* status) {
-    return batch_from_offsets(pcm, 2, offsets, lengths, n_songs, 2, 1, features_version, out, status, "blissgpu_analyze_batch_s16");
+    return batch_from_offsets(pcm, 2, offsets, lengths, n_songs, BLISSGPU_SAMPLE_S16, 1, features_version, out, status,
+                              "blissgpu_analyze_batch_s16");
 }
 
 int blissgpu_analyze_batch_interleaved(const void* pcm, int sample_format, uint32_t channels, const uint64_t* offsets,
                                        const uint64_t* lengths, uint32_t n_songs, uint32_t features_version, float* out,
                                        int32_t* status) {
-    if (sample_format != BLISSGPU_SAMPLE_F32 && sample_format != BLISSGPU_SAMPLE_S16)
-        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_batch_interleaved", "sample_format must be F32 or S16");
+    if (!known_format(sample_format))
+        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_batch_interleaved", "sample_format must be F32, S16 or S32");
     if (channels == 0 || channels > 8) return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_batch_interleaved", "channels must be 1..8");
-    const int bytes = sample_format == BLISSGPU_SAMPLE_F32 ? 4 : 2;
-    return batch_from_offsets(pcm, (size_t)bytes * channels, offsets, lengths, n_songs, bytes, channels, features_version, out,
-                              status, "blissgpu_analyze_batch_interleaved");
+    const int bytes = sample_format == BLISSGPU_SAMPLE_S16 ? 2 : 4;
+    return batch_from_offsets(pcm, (size_t)bytes * channels, offsets, lengths, n_songs, sample_format, channels, features_version,
+                              out, status, "blissgpu_analyze_batch_interleaved");
+}
+
+int blissgpu_analyze_batch_decoded(const blissgpu_decoded_song* songs, uint32_t n_songs, uint32_t features_version, float* out,
+                                   int32_t* status) {
+    const char* who = "blissgpu_analyze_batch_decoded";
+    if (n_songs && (!songs || !out)) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
+    if (!blissgpu_feature_count(features_version)) return fail(BLISSGPU_ERR_INVALID, who, "features_version must be 1 or 2");
+    if (n_songs == 0) return BLISSGPU_OK;
+    std::vector<bg::FeedSong> feed(n_songs);
+    for (uint32_t i = 0; i < n_songs; i++) {
+        const blissgpu_decoded_song& d = songs[i];
+        if (d.channels == 0 || d.channels > 8) return fail(BLISSGPU_ERR_INVALID, who, "channels must be 1..8");
+        if (!known_format(d.sample_format)) return fail(BLISSGPU_ERR_INVALID, who, "sample_format must be F32, S16 or S32");
+        feed[i] = bg::FeedSong{d.pcm, d.frames, d.sample_rate, (uint8_t)d.sample_format, (uint8_t)d.channels};
+    }
+    DeviceRestore restore;
+    blissgpu_ctx* c;
+    const int rc = default_ctx(&c);
+    if (rc) return rc;
+    return analyze_host_songs(c, feed.data(), n_songs, features_version, out, status, who);
 }
 
 int blissgpu_analyze(const float* pcm, uint64_t len, uint32_t features_version, float* out, int32_t* status) {
-    return analyze_one(pcm, len, 4, 1, features_version, out, status, "blissgpu_analyze");
+    return analyze_one(pcm, len, BLISSGPU_SAMPLE_F32, 1, bg::SWR_OUT_RATE, features_version, out, status, "blissgpu_analyze");
 }
 
 int blissgpu_analyze_interleaved(const void* pcm, int sample_format, uint32_t channels, uint64_t frames,
                                  uint32_t features_version, float* out, int32_t* status) {
-    if (sample_format != BLISSGPU_SAMPLE_F32 && sample_format != BLISSGPU_SAMPLE_S16)
-        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_interleaved", "sample_format must be F32 or S16");
-    return analyze_one(pcm, frames, sample_format == BLISSGPU_SAMPLE_F32 ? 4 : 2, channels, features_version, out, status,
+    if (!known_format(sample_format))
+        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_interleaved", "sample_format must be F32, S16 or S32");
+    return analyze_one(pcm, frames, sample_format, channels, bg::SWR_OUT_RATE, features_version, out, status,
                        "blissgpu_analyze_interleaved");
+}
+
+int blissgpu_analyze_decoded(const void* pcm, int sample_format, uint32_t channels, uint64_t frames, uint32_t sample_rate,
+                             uint32_t features_version, float* out, int32_t* status) {
+    if (!known_format(sample_format))
+        return fail(BLISSGPU_ERR_INVALID, "blissgpu_analyze_decoded", "sample_format must be F32, S16 or S32");
+    return analyze_one(pcm, frames, sample_format, channels, sample_rate, features_version, out, status, "blissgpu_analyze_decoded");
 }
 
 int blissgpu_pcm_s16_to_f32_device(blissgpu_ctx* c, const int16_t* d_in, uint64_t n, float* d_out) {
     if (!c || (n && (!d_in || !d_out))) return fail(BLISSGPU_ERR_INVALID, "blissgpu_pcm_s16_to_f32_device", "NULL argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    launch_pcm_convert(d_in, 2, 1, d_out, n, c->stream);
+    launch_pcm_convert(d_in, BLISSGPU_SAMPLE_S16, 1, d_out, n, c->stream);
     HIP_TRY(hipGetLastError());
     return BLISSGPU_OK;
 }
@@ -734,13 +869,46 @@ int blissgpu_pcm_s16_to_f32_device(blissgpu_ctx* c, const int16_t* d_in, uint64_
 int blissgpu_pcm_downmix_device(blissgpu_ctx* c, const void* d_in, int sample_format, uint32_t channels, uint64_t frames,
                                 float* d_out) {
     if (!c || (frames && (!d_in || !d_out))) return fail(BLISSGPU_ERR_INVALID, "blissgpu_pcm_downmix_device", "NULL argument");
-    if ((sample_format != BLISSGPU_SAMPLE_F32 && sample_format != BLISSGPU_SAMPLE_S16) || channels == 0 || channels > 8)
+    if (!known_format(sample_format) || channels == 0 || channels > 8)
         return fail(BLISSGPU_ERR_INVALID, "blissgpu_pcm_downmix_device", "bad sample_format / channels");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    launch_pcm_convert(d_in, sample_format == BLISSGPU_SAMPLE_F32 ? 4 : 2, channels, d_out, frames, c->stream);
+    launch_pcm_convert(d_in, sample_format, channels, d_out, frames, c->stream);
     HIP_TRY(hipGetLastError());
     return BLISSGPU_OK;
+}
+
+uint64_t blissgpu_resampled_len(uint64_t frames, uint32_t sample_rate) {
+    if (sample_rate == bg::SWR_OUT_RATE) return frames;
+    bg::SwrPlan p;
+    if (sample_rate > bg::MAX_SAMPLE_RATE || !bg::swr_make_plan(sample_rate, &p)) return 0;
+    return bg::swr_out_len(p, frames);
+}
+
+int blissgpu_resample_filter(uint32_t sample_rate, float* bank, uint64_t max_elems, uint32_t* taps, uint32_t* phase_count) {
+    bg::SwrPlan p;
+    if (sample_rate == 0 || sample_rate > bg::MAX_SAMPLE_RATE || !bg::swr_make_plan(sample_rate, &p))
+        return fail(BLISSGPU_ERR_INVALID, "blissgpu_resample_filter", "sample_rate must be 1 .. 768000 Hz");
+    if (taps) *taps = (uint32_t)p.taps;
+    if (phase_count) *phase_count = (uint32_t)p.phase_count;
+    if (bank) {
+        std::vector<float> b;
+        bg::swr_make_filter(p, b);
+        memcpy(bank, b.data(), sizeof(float) * (size_t)std::min<uint64_t>(max_elems, b.size()));
+    }
+    return BLISSGPU_OK;
+}
+
+int blissgpu_pcm_decode_device(blissgpu_ctx* c, const void* d_in, int sample_format, uint32_t channels, uint64_t frames,
+                               uint32_t sample_rate, float* d_out) {
+    const char* who = "blissgpu_pcm_decode_device";
+    if (!c || (frames && (!d_in || !d_out))) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
+    if (!known_format(sample_format) || channels == 0 || channels > 8) return fail(BLISSGPU_ERR_INVALID, who, "bad sample_format / channels");
+    if (sample_rate == 0 || sample_rate > bg::MAX_SAMPLE_RATE) return fail(BLISSGPU_ERR_INVALID, who, "sample_rate must be 1 .. 768000 Hz");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    return bg::enqueue_decode(c, d_in, sample_format, channels, frames, sample_rate, d_out, blissgpu_resampled_len(frames, sample_rate),
+                              c->stream, who);
 }
 
 }  // extern "C"

@@ -13,12 +13,15 @@ from typing import Iterable, Iterator, Optional, Tuple, Union
 import numpy as np
 
 from .song import (AnalysisOptions, BlissError, DecodingError, FeaturesVersion, SAMPLE_RATE, Song,
-                   analyze_batch)
+                   analyze_batch, analyze_decoded_batch, resampled_len)
 
 
 @dataclass
 class PreAnalyzedSong:
-    """src/song/decoder.rs:34-65: decoded mono 22 050 Hz f32 samples + tags."""
+    """src/song/decoder.rs:34-65: decoded samples + tags.  The reference's decoders deliver mono 22 050 Hz f32; here a
+    decoder may stop earlier and hand over what the codec produced -- [frames, channels] int16 / int32 / float32 at
+    `sample_rate` -- and the conversion FFmpegDecoder does on the CPU (libswresample, src/song/decoder/ffmpeg.rs:36-109)
+    runs on the device with the analysis."""
     path: str = ""
     artist: Optional[str] = None
     title: Optional[str] = None
@@ -29,6 +32,7 @@ class PreAnalyzedSong:
     genre: Optional[str] = None
     duration: float = 0.0
     sample_array: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    sample_rate: int = SAMPLE_RATE
 
     def _song(self, analysis, version) -> Song:
         return Song(path=self.path, artist=self.artist, title=self.title, album=self.album,
@@ -37,7 +41,10 @@ class PreAnalyzedSong:
 
     def to_song_with_options(self, analysis_options: AnalysisOptions) -> Song:
         """src/song/decoder.rs:85-101"""
-        analysis = Song.analyze_with_options(self.sample_array, analysis_options)
+        if self.sample_rate == SAMPLE_RATE:
+            analysis = Song.analyze_with_options(self.sample_array, analysis_options)
+        else:
+            analysis = Song.analyze_decoded(self.sample_array, self.sample_rate, analysis_options)
         return self._song(analysis, FeaturesVersion(analysis_options.features_version))
 
 
@@ -69,7 +76,11 @@ class Decoder(abc.ABC):
         pending = []
 
         def flush():
-            results = analyze_batch([p.sample_array for p in pending], analysis_options)
+            if all(p.sample_rate == SAMPLE_RATE for p in pending):
+                results = analyze_batch([p.sample_array for p in pending], analysis_options)
+            else:
+                results = analyze_decoded_batch([p.sample_array for p in pending], [p.sample_rate for p in pending],
+                                                analysis_options)
             for pre, res in zip(pending, results):
                 yield pre.path, (res if isinstance(res, BlissError) else pre._song(res, version))
             pending.clear()
@@ -90,23 +101,25 @@ class Decoder(abc.ABC):
 
 
 class RawPcmDecoder(Decoder):
-    """Decoder for already-decoded 22 050 Hz PCM: `.npy` (float32 or int16; 1-D mono or [frames, channels]) and 16-bit
-    `.wav` (any channel count).  int16 samples and extra channels are passed on as they are: the s16 -> f32 widening
-    (sample / 32768, FFmpeg's conversion) and the mono downmix ((L + R) * SQRT_2 / 2, src/song/decoder/symphonia.rs:
-    281-285) run on the device.  Resampling is not done: other sample rates are a DecodingError."""
+    """Decoder for already-decoded PCM: `.npy` (float32, int16 or int32; 1-D mono or [frames, channels]; 22 050 Hz) and
+    16-bit `.wav` (any channel count, ANY sample rate).  Samples are passed on as the file holds them: the widening
+    (sample / 32768, FFmpeg's conversion), the mono downmix and the resampling to 22 050 Hz (libswresample's default
+    resampler, as FFmpegDecoder uses it: src/song/decoder/ffmpeg.rs:36-109) run on the device."""
 
     @classmethod
     def decode(cls, path: str) -> PreAnalyzedSong:
+        rate = SAMPLE_RATE
         try:
             if path.endswith(".npy"):
                 a = np.load(path)
                 if a.ndim not in (1, 2) or (a.ndim == 2 and not 1 <= a.shape[1] <= 8):
                     raise DecodingError("expected [frames] or [frames, channels <= 8] samples")
-                samples = a if a.dtype == np.int16 else a.astype(np.float32)
+                samples = a if a.dtype in (np.int16, np.int32) else a.astype(np.float32)
             else:
                 with wave.open(path, "rb") as w:
-                    if w.getframerate() != SAMPLE_RATE or w.getsampwidth() != 2 or not 1 <= w.getnchannels() <= 8:
-                        raise DecodingError("only 22050 Hz s16 wav is supported by RawPcmDecoder")
+                    if w.getsampwidth() != 2 or not 1 <= w.getnchannels() <= 8:
+                        raise DecodingError("only s16 wav is supported by RawPcmDecoder")
+                    rate = w.getframerate()
                     samples = np.frombuffer(w.readframes(w.getnframes()), "<i2")
                     if w.getnchannels() > 1:
                         samples = samples.reshape(-1, w.getnchannels())
@@ -114,4 +127,5 @@ class RawPcmDecoder(Decoder):
             raise
         except Exception as e:
             raise DecodingError(f"while opening format for file '{path}': {e}")
-        return PreAnalyzedSong(path=path, sample_array=samples, duration=samples.shape[0] / SAMPLE_RATE)
+        return PreAnalyzedSong(path=path, sample_array=samples, sample_rate=rate,
+                               duration=resampled_len(samples.shape[0], rate) / SAMPLE_RATE)

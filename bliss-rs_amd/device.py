@@ -200,6 +200,26 @@ class Context:
         self._post()
         return out
 
+    def pcm_decode(self, pcm, sample_rate: int, out=None):
+        """On-device conversion of decoder output (1-D mono or [frames, channels]; int16 / int32 / float32) at `sample_rate`
+        Hz to the mono 22 050 Hz f32 stream Song::analyze takes: libswresample's default resampler as FFmpegDecoder drives
+        it (src/song/decoder/ffmpeg.rs:36-109), bit for bit (Adler-32 pins of ffmpeg.rs:433-452, 471-476)."""
+        torch = self.torch
+        assert pcm.is_cuda and pcm.dim() in (1, 2) and pcm.dtype in (torch.int16, torch.int32, torch.float32)
+        pcm = pcm.contiguous()
+        frames = pcm.shape[0]
+        channels = 1 if pcm.dim() == 1 else pcm.shape[1]
+        n_out = int(self._L.blissgpu_resampled_len(frames, int(sample_rate)))
+        if out is None:
+            out = torch.empty((n_out,), dtype=torch.float32, device=pcm.device)
+        assert out.numel() >= n_out
+        fmt = {torch.int16: _ffi.SAMPLE_S16, torch.int32: _ffi.SAMPLE_S32, torch.float32: _ffi.SAMPLE_F32}[pcm.dtype]
+        self._pre()
+        _ffi.check(self._L.blissgpu_pcm_decode_device(self._h, C.c_void_p(pcm.data_ptr()), fmt, channels, frames,
+                                                      int(sample_rate), C.c_void_p(out.data_ptr())))
+        self._post()
+        return out[:n_out]
+
     # ---- playlist ordering on device-resident feature matrices (src/playlist.rs:24-59, 256-326) ----
     def _pl_args(self, seeds, cand, M):
         torch = self.torch

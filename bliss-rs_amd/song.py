@@ -159,13 +159,67 @@ def _as_pcm(sample_array) -> np.ndarray:
     s16 -> flt conversion), everything else becomes float32; 1-D = mono, 2-D = [frames, channels] interleaved
     (downmixed on the device like the reference's decoders, src/song/decoder/symphonia.rs:266-300)."""
     a = np.asarray(sample_array)
-    if a.dtype != np.int16:
+    if a.dtype not in (np.int16, np.int32):  # int32 = FFmpeg's S32 (24-bit streams left-justified): (float)s / 2^31 on the device
         a = a.astype(np.float32, copy=False)
     if a.ndim == 2 and a.shape[1] == 1:
         a = a[:, 0]
     if a.ndim not in (1, 2):
         raise ProviderError("sample arrays must be 1-D (mono) or 2-D [frames, channels]")
     return np.ascontiguousarray(a)
+
+
+def _fmt_of(a: np.ndarray) -> int:
+    return _ffi.SAMPLE_S16 if a.dtype == np.int16 else (_ffi.SAMPLE_S32 if a.dtype == np.int32 else _ffi.SAMPLE_F32)
+
+
+def resampled_len(frames: int, sample_rate: int) -> int:
+    """Samples at 22 050 Hz that `frames` frames at `sample_rate` become (libswresample's count; device-free)."""
+    return int(_ffi.lib().blissgpu_resampled_len(int(frames), int(sample_rate)))
+
+
+def _results(out, status, version):
+    results = []
+    for i in range(len(status)):
+        if status[i] == _ffi.SONG_OK:
+            results.append(Analysis(out[i], version))
+        elif status[i] == _ffi.SONG_TOO_SHORT:
+            results.append(AnalysisError("empty or too short song."))
+        else:
+            results.append(AnalysisError(f"analysis failed with status {int(status[i])}"))
+    return results
+
+
+def analyze_decoded_batch(sample_arrays: Sequence[np.ndarray], sample_rates, options: Optional[AnalysisOptions] = None):
+    """Decoder output at ANY sample rate -> analysis: what FFmpegDecoder::decode + Song::analyze do together
+    (src/song/decoder/ffmpeg.rs:36-109, src/song/decoder.rs:85-101), with libswresample's conversion to mono 22 050 Hz
+    done on the device, bit for bit.  sample_rates: one rate for all songs or one per song."""
+    options = options or AnalysisOptions()
+    version = FeaturesVersion(options.features_version)
+    arrays = [_as_pcm(a) for a in sample_arrays]
+    n = len(arrays)
+    if n == 0:
+        return []
+    rates = [int(sample_rates)] * n if np.isscalar(sample_rates) else [int(r) for r in sample_rates]
+    if len(rates) != n:
+        raise ProviderError("one sample rate per song")
+    d = version.feature_count()
+    out = np.empty((n, d), np.float32)
+    status = np.zeros(n, np.int32)
+    L = _ffi.lib()
+    keep = [a if a.size else np.zeros(1, a.dtype) for a in arrays]
+    if n == 1:
+        a = arrays[0]
+        st = C.c_int32(0)
+        _ffi.check(L.blissgpu_analyze_decoded(keep[0].ctypes.data, _fmt_of(a), 1 if a.ndim == 1 else a.shape[1], a.shape[0],
+                                              rates[0], int(version), out.ctypes.data, C.byref(st)))
+        status[0] = st.value
+    else:
+        songs = (_ffi.DecodedSong * n)()
+        for i, a in enumerate(arrays):
+            songs[i] = _ffi.DecodedSong(keep[i].ctypes.data, a.shape[0], rates[i], 1 if a.ndim == 1 else a.shape[1], _fmt_of(a))
+        _ffi.check(L.blissgpu_analyze_batch_decoded(songs, n, int(version), out.ctypes.data,
+                                                    status.ctypes.data_as(C.POINTER(C.c_int32))))
+    return _results(out, status, version)
 
 
 def analyze_batch(sample_arrays: Sequence[np.ndarray], options: Optional[AnalysisOptions] = None):
@@ -186,9 +240,8 @@ def analyze_batch(sample_arrays: Sequence[np.ndarray], options: Optional[Analysi
     # one device batch per (sample format, channel count) class -- normally there is exactly one
     classes = {}
     for i, a in enumerate(arrays):
-        classes.setdefault((a.dtype == np.int16, 1 if a.ndim == 1 else a.shape[1]), []).append(i)
-    for (s16, channels), idx in classes.items():
-        fmt = _ffi.SAMPLE_S16 if s16 else _ffi.SAMPLE_F32
+        classes.setdefault((_fmt_of(a), 1 if a.ndim == 1 else a.shape[1]), []).append(i)
+    for (fmt, channels), idx in classes.items():
         if len(idx) == 1:
             a = arrays[idx[0]]
             buf = a if a.size else np.zeros(1, a.dtype)
@@ -204,7 +257,7 @@ def analyze_batch(sample_arrays: Sequence[np.ndarray], options: Optional[Analysi
         offsets[1:] = np.cumsum(lengths)[:-1]
         pcm = np.concatenate([arrays[i].reshape(-1) for i in idx])
         if pcm.size == 0:
-            pcm = np.zeros(1, np.int16 if s16 else np.float32)
+            pcm = np.zeros(1, arrays[idx[0]].dtype)
         res = np.empty((len(idx), d), np.float32)
         st = np.empty(len(idx), np.int32)
         _ffi.check(L.blissgpu_analyze_batch_interleaved(
@@ -213,15 +266,7 @@ def analyze_batch(sample_arrays: Sequence[np.ndarray], options: Optional[Analysi
             st.ctypes.data_as(C.POINTER(C.c_int32))))
         out[idx] = res
         status[idx] = st
-    results = []
-    for i in range(n):
-        if status[i] == _ffi.SONG_OK:
-            results.append(Analysis(out[i], version))
-        elif status[i] == _ffi.SONG_TOO_SHORT:
-            results.append(AnalysisError("empty or too short song."))
-        else:
-            results.append(AnalysisError(f"analysis failed with status {int(status[i])}"))
-    return results
+    return _results(out, status, version)
 
 
 @dataclass
@@ -249,6 +294,15 @@ class Song:
     def analyze_with_options(sample_array, analysis_options: AnalysisOptions) -> Analysis:
         """src/song/mod.rs:413-508.  Raises AnalysisError("empty or too short song.") for len < 8192."""
         res = analyze_batch([sample_array], analysis_options)[0]
+        if isinstance(res, BlissError):
+            raise res
+        return res
+
+    @staticmethod
+    def analyze_decoded(sample_array, sample_rate: int, analysis_options: Optional[AnalysisOptions] = None) -> Analysis:
+        """Decoder output at `sample_rate` Hz (1-D mono or [frames, channels]; float32 / int16 / int32): the conversion
+        FFmpegDecoder does on the CPU (src/song/decoder/ffmpeg.rs:36-109) runs on the device, then Song::analyze."""
+        res = analyze_decoded_batch([sample_array], sample_rate, analysis_options)[0]
         if isinstance(res, BlissError):
             raise res
         return res

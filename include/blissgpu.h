@@ -54,7 +54,9 @@ extern "C" {
 
 /* ---- sample formats of the PCM feed (decoder output before the mono f32 conversion) ---- */
 #define BLISSGPU_SAMPLE_F32 0
-#define BLISSGPU_SAMPLE_S16 1
+#define BLISSGPU_SAMPLE_S16 1         /* sample / 32768 */
+#define BLISSGPU_SAMPLE_S32 2         /* (float)sample / 2^31: how FFmpeg delivers 24- and 32-bit streams */
+#define BLISSGPU_SAMPLE_RATE 22050u   /* SAMPLE_RATE (src/lib.rs:140): the rate Song::analyze works at */
 
 /* ---- distance metrics (src/playlist.rs:65-79, 129-142) ---- */
 #define BLISSGPU_METRIC_EUCLIDEAN 0
@@ -96,7 +98,8 @@ int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
                                            songs (at most 8), the contraction of piece k beside the tuning estimate of piece
                                            k + 1; 0 / 1 = unsplit (default: see DESIGN.md section 3b) */
 #define BLISSGPU_OPT_DEBUG_CHROMA 5     /* 1: the contraction also keeps chroma_stft's matrix and the assembly the interval
-                                           means of the last chunk for the CHROMA / INTERVAL taps below (96 B per frame) */
+                                           means of the chunk for the CHROMA / INTERVAL taps below (96 B per frame); such a
+                                           batch must fit ONE chunk (BLISSGPU_ERR_INVALID otherwise) */
 int blissgpu_ctx_set_option(blissgpu_ctx *ctx, int option, int64_t value);
 
 /* The default contexts: how many there are, the HIP ordinal of the k-th, and how many coalesced batches of single-song
@@ -105,10 +108,16 @@ int blissgpu_default_device_count(void);
 int blissgpu_default_device(int k);
 uint64_t blissgpu_default_device_batches(int k);
 /* How long a single-song call (blissgpu_analyze / _interleaved) may wait for a default context to pick it up before it
- * fails with BLISSGPU_ERR_TIMEOUT instead of blocking (default 600 000 ms; <= 0 restores the default).  A default context
+ * fails with BLISSGPU_ERR_TIMEOUT instead of blocking (default 600 000 ms; <= 0 restores the default; clamped to ten
+ * years).  A default context
  * whose device cannot give a context is retired -- its traffic goes to the others -- and only when all are retired do the
  * calls fail, with the creation error. */
 int blissgpu_set_single_song_timeout_ms(int64_t ms);
+/* A default context that could not be created is not retried on every call: a failure that cannot change (no such device,
+ * another architecture) is remembered for good, anything else (no memory for the tables while another process holds the
+ * device, a HIP error) is tried again after a back-off of 100 ms .. 5 s, and a retired seat of the single-song front is offered
+ * traffic again after 1 s .. 64 s.  blissgpu_default_reset() forgets every remembered failure and revives every seat now. */
+int blissgpu_default_reset(void);
 
 uint32_t blissgpu_feature_count(uint32_t features_version); /* FeaturesVersion::feature_count, src/lib.rs:181-186 */
 
@@ -118,11 +127,11 @@ uint32_t blissgpu_feature_count(uint32_t features_version); /* FeaturesVersion::
  * contexts; safe to call from any number of threads (concurrent calls are coalesced into device batches, one in flight
  * per device). */
 int blissgpu_analyze(const float *pcm, uint64_t len, uint32_t features_version, float *out, int32_t *status);
-/* Same for raw decoder output: `frames` frames of `channels` interleaved samples (BLISSGPU_SAMPLE_F32 / _S16) at
+/* Same for raw decoder output: `frames` frames of `channels` interleaved samples (BLISSGPU_SAMPLE_F32 / _S16 / _S32) at
  * 22 050 Hz.  s16 is widened with sample / 32768 and channels are downmixed ON THE DEVICE exactly like the reference's
  * decoders: stereo -> (L + R) * SQRT_2 / 2, more channels -> their mean (src/song/decoder/symphonia.rs:266-300; pinned
- * on data/s16_stereo_22_5kHz.flac by Adler-32 0x1d7b2d6d, src/song/decoder/ffmpeg.rs:448-452).  Resampling is NOT
- * done here: the caller delivers 22 050 Hz. */
+ * on data/s16_stereo_22_5kHz.flac by Adler-32 0x1d7b2d6d, src/song/decoder/ffmpeg.rs:448-452).  The caller delivers
+ * 22 050 Hz here; blissgpu_analyze_decoded takes any rate. */
 int blissgpu_analyze_interleaved(const void *pcm, int sample_format, uint32_t channels, uint64_t frames,
                                  uint32_t features_version, float *out, int32_t *status);
 
@@ -145,10 +154,45 @@ int blissgpu_analyze_batch_s16(const int16_t *pcm, const uint64_t *offsets, cons
 int blissgpu_analyze_batch_interleaved(const void *pcm, int sample_format, uint32_t channels, const uint64_t *offsets,
                                        const uint64_t *lengths, uint32_t n_songs, uint32_t features_version, float *out,
                                        int32_t *status);
+/* ---- decoder output at ANY sample rate (src/song/decoder/ffmpeg.rs:36-109) ----
+ * The reference's FFmpegDecoder hands every decoded frame to libswresample with its default options (Kaiser-windowed sinc,
+ * filter_size 32, cutoff 0.97, exact rational phases) and asks for mono f32 at 22 050 Hz.  These entry points take what the
+ * DECODER delivers -- `frames` frames of `channels` interleaved samples at `sample_rate` Hz -- and do that conversion ON THE
+ * DEVICE, bit for bit: widening (s16 / s32), libswresample's resampler with the summation order of its AVX2 + FMA3 kernel,
+ * the stream mirrored at both ends, stereo = each channel resampled, then l * sqrt(1/2) + r * sqrt(1/2) (more channels: the
+ * sequential mean first, as src/song/decoder/symphonia.rs:291-297, then the resampler).  sample_rate 22 050 is the pass-through
+ * of blissgpu_analyze_interleaved.  Pinned by the reference's own Adler-32 decoder tests: 0xa0f8b8af
+ * (data/s32_mono_44_1_kHz.flac), 0xbbcba1cf (s32_stereo_44_1_kHz.flac) -- ffmpeg.rs:433-445 -- and 0xd594429c (no_channel.wav,
+ * :471-476); with it the three CUE tracks of data/testcue.flac give the 3 x 23 features src/cue.rs:270-415 asserts.
+ * Rates other than 44 100 Hz run the same code but no reference test holds a number for them. */
+int blissgpu_analyze_decoded(const void *pcm, int sample_format, uint32_t channels, uint64_t frames, uint32_t sample_rate,
+                             uint32_t features_version, float *out, int32_t *status);
+/* Bulk form: every song with its own buffer, format, channel count and rate (a library is a mix of 44.1 and 48 kHz, mono
+ * and stereo files).  The compute half of Decoder::analyze_paths_with_options (src/song/decoder.rs:278-332) for a host that
+ * keeps its decoder and drops the resampler. */
+typedef struct blissgpu_decoded_song {
+    const void *pcm;        /* host memory: frames x channels interleaved samples */
+    uint64_t frames;
+    uint32_t sample_rate;   /* Hz, 1 .. 768 000 */
+    uint16_t channels;      /* 1 .. 8 */
+    uint16_t sample_format; /* BLISSGPU_SAMPLE_* */
+} blissgpu_decoded_song;
+int blissgpu_analyze_batch_decoded(const blissgpu_decoded_song *songs, uint32_t n_songs, uint32_t features_version, float *out,
+                                   int32_t *status);
+/* Number of 22 050 Hz samples `frames` input frames become (device-free; = frames at 22 050 Hz, 0 when the stream is shorter
+ * than the resampler's start-up needs or the rate is out of range). */
+uint64_t blissgpu_resampled_len(uint64_t frames, uint32_t sample_rate);
+/* The resampler's filter bank for one input rate (device-free; test tap): *taps x *phase_count floats, phase-major; bank
+ * may be NULL to query the sizes, at most max_elems floats are written. */
+int blissgpu_resample_filter(uint32_t sample_rate, float *bank, uint64_t max_elems, uint32_t *taps, uint32_t *phase_count);
+
 /* The conversions alone, device to device (asynchronous on the context's stream). */
 int blissgpu_pcm_s16_to_f32_device(blissgpu_ctx *ctx, const int16_t *d_in, uint64_t n_samples, float *d_out);
 int blissgpu_pcm_downmix_device(blissgpu_ctx *ctx, const void *d_in, int sample_format, uint32_t channels, uint64_t frames,
                                 float *d_out);
+/* decoder output at sample_rate -> mono 22 050 Hz f32; d_out holds blissgpu_resampled_len(frames, sample_rate) samples */
+int blissgpu_pcm_decode_device(blissgpu_ctx *ctx, const void *d_in, int sample_format, uint32_t channels, uint64_t frames,
+                               uint32_t sample_rate, float *d_out);
 
 /* Device-resident form: d_pcm / d_out / d_status are HIP device pointers (d_status may be NULL),
  * offsets / lengths stay on the host (they size the launch).  Asynchronous on the context's

@@ -114,6 +114,24 @@ long bo_dedup_playlist(const float *songs, size_t n, size_t d, int metric, const
                        const uint8_t *same_meta /* n*n or NULL */, uint32_t *kept /* n */);
 int bo_variance_weight_matrix(const float *seeds, size_t n_seeds, size_t d, float *m /* d*d */);
 
+
+/* ---- the decoder's conversion to mono 22 050 Hz f32: libswresample as FFmpegDecoder drives it
+ * (src/song/decoder/ffmpeg.rs:36-109); restated from FFmpeg's published source, see bliss_oracle.c.
+ * Pinned by the reference's Adler-32 decoder tests (ffmpeg.rs:433-452, 471-476). ---- */
+typedef struct {
+    uint32_t in_rate;
+    int taps, phase_count, center;
+    uint64_t dst_incr, src_incr; /* output k sits at floor(k dst_incr / src_incr) / phase_count input samples */
+    double factor;
+} bo_swr_plan_t;
+int bo_swr_plan(uint32_t in_rate, bo_swr_plan_t *p);
+void bo_swr_filter(const bo_swr_plan_t *p, float *bank /* [phase_count][taps] */);
+uint64_t bo_swr_out_len(uint64_t n_in, uint32_t in_rate);
+void bo_swr_resample(const float *x, uint64_t n, uint32_t in_rate, float *out /* bo_swr_out_len */);
+/* sample_format 0 f32 / 1 s16 / 2 s32; interleaved channels; returns the sample count written to out */
+uint64_t bo_decode_to_mono(const void *pcm, int sample_format, uint32_t channels, uint64_t frames, uint32_t in_rate,
+                           float *out);
+
 /* ---- bench/test input generator (not part of the reference): Philox4x32-10 white noise,
  * uniform [-0.5, 0.5), key = (0x5EED0000 + song_index, 0), counter = sample_index / 4 ---- */
 void bo_white_noise(uint32_t song_index, size_t n, float *out);

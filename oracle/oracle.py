@@ -20,6 +20,12 @@ def build(force=False):
     return _SO
 
 
+class SwrPlan(C.Structure):
+    """bo_swr_plan_t"""
+    _fields_ = [("in_rate", C.c_uint32), ("taps", C.c_int), ("phase_count", C.c_int), ("center", C.c_int),
+                ("dst_incr", C.c_uint64), ("src_incr", C.c_uint64), ("factor", C.c_double)]
+
+
 _lib = None
 
 
@@ -79,6 +85,11 @@ def lib():
             "bo_dedup_playlist": (C.c_long, [f32p, sz, sz, C.c_int, f32p, C.c_float, C.POINTER(C.c_uint8),
                                              C.POINTER(C.c_uint32)]),
             "bo_variance_weight_matrix": (C.c_int, [f32p, sz, sz, f32p]),
+            "bo_swr_plan": (C.c_int, [C.c_uint32, C.POINTER(SwrPlan)]),
+            "bo_swr_filter": (None, [C.POINTER(SwrPlan), f32p]),
+            "bo_swr_out_len": (C.c_uint64, [C.c_uint64, C.c_uint32]),
+            "bo_swr_resample": (None, [f32p, C.c_uint64, C.c_uint32, f32p]),
+            "bo_decode_to_mono": (C.c_uint64, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, f32p]),
             "bo_white_noise": (None, [C.c_uint32, sz, f32p]),
             "bo_set_fft_double": (None, [C.c_int]),
         }
@@ -499,3 +510,31 @@ def white_noise(song_index, n):
 def set_fft_double(on):
     """tests only: FFTs evaluated in f64 then rounded -- measures sensitivity to FFT rounding"""
     lib().bo_set_fft_double(int(bool(on)))
+
+
+# ---- the decoder's conversion to mono 22 050 Hz f32 (libswresample as FFmpegDecoder drives it, ffmpeg.rs:36-109) ----
+def swr_out_len(n_in, in_rate):
+    return int(lib().bo_swr_out_len(int(n_in), int(in_rate)))
+
+
+def swr_filter(in_rate):
+    """(bank[phase_count, taps] float32, plan)"""
+    p = SwrPlan()
+    if lib().bo_swr_plan(int(in_rate), C.byref(p)):
+        raise ValueError("bad rate")
+    bank = np.zeros((p.phase_count, p.taps), np.float32)
+    lib().bo_swr_filter(C.byref(p), _p(bank, C.c_float))
+    return bank, p
+
+
+def decode_to_mono(samples, in_rate):
+    """samples: 1-D mono or [frames, channels]; int16 / int32 (FFmpeg's S16 / S32) / float32 -> mono 22 050 Hz float32"""
+    a = np.ascontiguousarray(samples)
+    if a.dtype not in (np.int16, np.int32):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+    fmt = 1 if a.dtype == np.int16 else (2 if a.dtype == np.int32 else 0)
+    frames = a.shape[0]
+    channels = 1 if a.ndim == 1 else a.shape[1]
+    out = np.zeros(max(1, swr_out_len(frames, in_rate)), np.float32)
+    n = lib().bo_decode_to_mono(a.ctypes.data if a.size else None, fmt, channels, frames, int(in_rate), _p(out, C.c_float))
+    return out[:n]

@@ -44,3 +44,36 @@ def golden_pcm():
 @pytest.fixture(scope="session")
 def piano_pcm():
     return load_golden("librosa-decoded.npy")
+
+
+# ---- the reference's audio data files that are NOT at 22 050 Hz (inputs of the resampler row; tests/golden/make_fixtures.py)
+_DECODED = {}
+
+
+def decoded_audio(name):
+    """(samples, sample_rate): what FFmpeg's decoder hands to the resampler -- int16 for 16-bit files, int32 with 24-bit
+    samples left-justified (AV_SAMPLE_FMT_S32) for the 24-bit ones; 1-D mono or [frames, channels]."""
+    if name not in _DECODED:
+        path = os.path.join(GOLDEN, name)
+        if name.endswith(".wav"):
+            import wave
+
+            with wave.open(path, "rb") as w:
+                assert w.getsampwidth() == 2
+                a = np.frombuffer(w.readframes(w.getnframes()), "<i2").reshape(-1, w.getnchannels())
+                rate = w.getframerate()
+        else:
+            sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+            from flac_decode import decode_flac
+
+            a, rate, bps = decode_flac(path)
+            a = a.astype(np.int16) if bps == 16 else (a.astype(np.int64) << (32 - bps)).astype(np.int32)
+        _DECODED[name] = (np.ascontiguousarray(a[:, 0] if a.shape[1] == 1 else a), rate)
+    return _DECODED[name]
+
+
+def cue_bounds(index_mm_ss_ff, n_samples):
+    """BlissCueFile::get_songs (src/cue.rs:209-246): a track runs from its INDEX to the next track's, both as
+    (as_secs_f32() * SAMPLE_RATE as f32) as usize; the last one to the end of the decoded file."""
+    starts = [int(np.float32(m * 60 + s + f / 75.0) * np.float32(22050)) for m, s, f in index_mm_ss_ff]
+    return list(zip(starts, starts[1:] + [n_samples]))

@@ -5,7 +5,8 @@
 // traffic, that a request nobody picks up fails at its deadline instead of blocking -- and, by finishing at all within the
 // caller's timeout, that no caller is left waiting.  Built with -fsanitize=thread by the CPU suite.
 //     usage: test_front [threads] [calls] [seats] [batch_us] [scenario]
-//     scenario 0 = plain, 1 = one seat unusable, 2 = every seat unusable, 3 = a stuck leader and short deadlines
+//     scenario 0 = plain, 1 = one seat unusable, 2 = every seat unusable, 3 = a stuck leader and short deadlines,
+//              4 = one seat unusable for the first 150 ms only: its rest (20 ms, doubling) ends and it serves batches again
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -30,6 +31,9 @@ int main(int argc, char** argv) {
     const int S = argc > 3 ? std::atoi(argv[3]) : 4, batch_us = argc > 4 ? std::atoi(argv[4]) : 300;
     const int scenario = argc > 5 ? std::atoi(argv[5]) : 0;
     bg::CoalescingFront<Req> front;
+    // scenarios 1 - 3 count on a retired seat STAYING retired for the length of the run
+    front.set_revive_base(scenario == 4 ? std::chrono::milliseconds(20) : std::chrono::milliseconds(3600 * 1000));
+    const auto t_start = std::chrono::steady_clock::now();
     std::vector<std::atomic<int>> busy(S);
     std::vector<std::atomic<long>> batches(S), refused_calls(S);
     for (int s = 0; s < S; s++) { busy[s] = 0; batches[s] = 0; refused_calls[s] = 0; }
@@ -37,7 +41,8 @@ int main(int argc, char** argv) {
     std::atomic<bool> release_stuck{false};
     std::atomic<int> stuck_batches{0};
     auto run = [&](std::vector<Req*>& take, int seat) -> bool {
-        if (scenario == 2 || (scenario == 1 && seat == S / 2)) {      // this seat's device cannot give a context
+        const bool early = std::chrono::steady_clock::now() - t_start < std::chrono::milliseconds(150);
+        if (scenario == 2 || (scenario == 1 && seat == S / 2) || (scenario == 4 && seat == S / 2 && early)) {  // this seat's device cannot give a context
             refused_calls[seat]++;
             return false;
         }
@@ -81,6 +86,7 @@ int main(int argc, char** argv) {
                 if (o == bg::FRONT_NO_SEAT) no_seat++;
                 if (o == bg::FRONT_TIMED_OUT) timed_out++;
                 if ((c & 7) == (t & 7)) std::this_thread::sleep_for(std::chrono::microseconds(50 + 13 * (t % 5)));  // "decode"
+                if (scenario == 4) std::this_thread::sleep_for(std::chrono::milliseconds(1));  // (the run must outlast the rests)
             }
         });
     if (scenario == 3) {
@@ -102,5 +108,8 @@ int main(int argc, char** argv) {
         ok = ok && total == all && front.retired_seats() == 1 && refused_calls[S / 2] == 1 && batches[S / 2] == 0 && no_seat == 0;
     if (scenario == 2) ok = ok && total == 0 && no_seat == all && front.retired_seats() == S;
     if (scenario == 3) ok = ok && timed_out > 0 && total + timed_out == all && no_seat == 0;
+    if (scenario == 4)   // retired, tried again after each rest, and back in service once its device gives a context
+        ok = ok && total == all && no_seat == 0 && refused_calls[S / 2] >= 1 && refused_calls[S / 2] <= 4 && batches[S / 2] > 0 &&
+             front.retired_seats() == 0;
     return ok ? 0 : 1;
 }

@@ -2,7 +2,7 @@
 """Generate tests/golden/ from the reference's DATA files (run once, in the build container).
 
 Nothing here executes or copies reference *source*: it copies the small `.npy` data fixtures the
-reference's own unit tests load (data/*.npy), decodes two of its audio data files to raw PCM
+reference's own unit tests load (data/*.npy) and six of its audio data files, decodes two more audio data files to raw PCM
 with the test-tool FLAC decoder (tests/tools/flac_decode.py) and checks the decoded PCM against
 the Adler-32 values the reference pins (src/song/decoder/ffmpeg.rs:455-462, :524-527).
 The reference's known-answer literals (numbers asserted in its unit tests) are recorded in
@@ -39,8 +39,23 @@ NPY = [
 ]
 
 
+# Audio DATA files of the reference's decoder / CUE / timbral tests that are NOT at 22 050 Hz: inputs of the resampler
+# row.  Copied as they are (data, 3.3 MB together); the tests decode them with tests/tools/flac_decode.py
+# / the stdlib wave module.  What the reference pins on each is in reference_literals.json ("resample").
+AUDIO = [
+    "s32_mono_44_1_kHz.flac",    # src/song/decoder/ffmpeg.rs:433-438  Adler-32 0xa0f8b8af after FFmpeg's conversion
+    "s32_stereo_44_1_kHz.flac",  # :440-445  0xbbcba1cf
+    "no_channel.wav",            # :471-476  0xd594429c (44.1 kHz mono s16)
+    "testcue.flac",              # src/cue.rs:270-415  three tracks x 23 features (44.1 kHz stereo s16), with testcue.cue's indices
+    "tone_11080Hz.flac",         # src/timbral.rs:364-373, 430-439  centroid / rolloff of an 11 080 Hz tone (44.1 kHz mono s16)
+    "flush_test_52000.wav",      # src/song/decoder/symphonia.rs:713  48 kHz mono s16, 52 000 frames -> 23 888 samples
+]
+
+
 def main():
     for name in NPY:
+        shutil.copyfile(os.path.join(DATA, name), os.path.join(HERE, name))
+    for name in AUDIO:
         shutil.copyfile(os.path.join(DATA, name), os.path.join(HERE, name))
     # a library file as an older bliss-rs wrote it: the DATA file its own upgrade test loads
     # (src/library.rs:3935-4002, data/old_database.sql) -- rows + the old schema, no program text
@@ -113,6 +128,37 @@ def main():
             "v2_metric_zeros_ones": {"src": "src/lib.rs:283-290", "value": 3.4999998}},
         "adler32": {"s16_mono_22_5kHz": "0x5e01930b", "piano": "0xde831e82",
                     "src": "src/song/decoder/ffmpeg.rs:455-462,524-527"},
+        "resample": {
+            "_note": "FFmpegDecoder's output (libswresample, default options) on files that are not at 22 050 Hz",
+            "adler32": {"src": "src/song/decoder/ffmpeg.rs:433-452,471-476",
+                        "s32_mono_44_1_kHz.flac": "0xa0f8b8af", "s32_stereo_44_1_kHz.flac": "0xbbcba1cf",
+                        "no_channel.wav": "0xd594429c", "s16_stereo_22_5kHz.flac": "0x1d7b2d6d"},
+            "lengths": {"src": "src/song/decoder/symphonia.rs:384-402,700-733 (expected_output_len = ceil(ratio * len), equal to FFmpeg's)",
+                        "flush_test_52000.wav": 23888},
+            "cue": {"src": "src/cue.rs:270-415 (assert_eq on the whole Song), indices from data/testcue.cue: 0:00:00, 0:11:05, 0:16:69",
+                    "file": "testcue.flac", "index_mm_ss_ff": [[0, 0, 0], [0, 11, 5], [0, 16, 69]],
+                    "tracks": [
+                        [0.38463724, -0.85219246, -0.761946, -0.8904667, -0.63892543, -0.73945934, -0.80040205,
+                         -0.82372904, 0.33865356, 0.32481194, -0.3433048, -0.6278722, -0.2809375, 0.08685577,
+                         0.24455929, -0.5721703, 0.23292911, 0.19979906, -0.5859135, -0.06785172, -0.05990714,
+                         -0.58482605, -0.078823924],
+                        [0.18622077, -0.5989029, -0.5554645, -0.63438654, -0.24163479, -0.25766593, -0.40616918,
+                         -0.23334831, 0.76875293, 0.7785741, -0.10609609, -0.14194643, -0.21418405, -0.21676934,
+                         -0.20846015, -0.22077763, -0.0002696514, -0.00034928322, 0.0003143549, 0.00030446053,
+                         -0.47109652, -0.66400576, 0.15099311],
+                        [0.0024260283, 0.9874661, 0.97330654, -0.97244257, 0.99678576, -0.9961549, -0.98401415,
+                         -0.9269961, 0.7498772, 0.22429907, 0.9990841, -0.9723601, -0.973079, -0.97307926,
+                         -0.97308147, -0.9730794, -2.783537e-5, -2.7775764e-5, 3.1113625e-5, 2.4557114e-5,
+                         -0.9210111, -0.99999785, -0.99993163]]},
+            "tone_11080Hz": {"_note": "SpectralDesc over chunks_exact(HOP_SIZE) of the decoded (resampled) file",
+                             "centroid": {"src": "src/timbral.rs:430-439", "tol": 1e-5, "values": [0.97266, -0.9609926]},
+                             "rolloff": {"src": "src/timbral.rs:364-373", "tol": 1e-4, "values": [0.9967681, -0.99615175]}},
+            "analysis_symphonia_s32_stereo_44_1_kHz": {
+                "src": "src/song/mod.rs:645-684 (the reference's OTHER decoder, rubato resampler: its own tolerance is 0.1)", "tol": 0.1,
+                "values": [0.38463664, -0.85172224, -0.7607465, -0.8857495, -0.63906085, -0.73908424, -0.7890965,
+                           -0.8191868, 0.33856833, 0.3246863, -0.34292227, -0.62803173, -0.2809453, 0.08687115,
+                           0.2444489, -0.5723239, 0.23292565, 0.19979525, -0.58593845, -0.06783122, -0.060014784,
+                           -0.5848569, -0.07879859]}},
     }
     with open(os.path.join(HERE, "reference_literals.json"), "w") as f:
         json.dump(literals, f, indent=1)

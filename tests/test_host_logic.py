@@ -311,14 +311,16 @@ TSAN_CXX = "/opt/rocm/lib/llvm/bin/clang++"   # (g++ 11's libtsan does not know 
 def test_coalescing_front_under_thread_sanitizer(tmp_path):
     """The same test built with -fsanitize=thread, through every scenario of tests/cpp/test_front.cpp: plain (random batch
     durations, leaders that fail mid-batch), one seat whose device cannot give a context (retired after ONE attempt, all
-    its traffic served elsewhere), every seat unusable (every call refused, none blocks), and leaders that hang while the
-    queued callers come back by themselves at their deadline.  No data race, no lock-order report, exit code 0."""
+    its traffic served elsewhere), every seat unusable (every call refused, none blocks), leaders that hang while the
+    queued callers come back by themselves at their deadline, and a seat that is unusable at first and serves batches
+    again once its rest is over.  No data race, no lock-order report, exit code 0."""
     exe = tmp_path / "test_front_tsan"
     subprocess.check_call([TSAN_CXX, "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=thread",
                            os.path.join(ROOT, "tests", "cpp", "test_front.cpp"), "-o", str(exe)])
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
     for args in (["32", "300", "1", "300", "0"], ["32", "300", "4", "300", "0"], ["32", "300", "8", "300", "0"],
-                 ["32", "200", "4", "300", "1"], ["16", "50", "4", "300", "2"], ["16", "60", "3", "300", "3"]):
+                 ["32", "200", "4", "300", "1"], ["16", "50", "4", "300", "2"], ["16", "60", "3", "300", "3"],
+                 ["32", "400", "4", "300", "4"]):
         out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=300, env=env)
         assert out.returncode == 0, (args, out.stdout[-1500:], out.stderr[-3000:])
         assert "ThreadSanitizer" not in out.stderr, (args, out.stderr[-3000:])

@@ -1,0 +1,141 @@
+"""Row f1's resampler on the CPU side (no GPU): the oracle's restatement of libswresample as FFmpegDecoder drives it
+(src/song/decoder/ffmpeg.rs:36-109) against everything the reference's tests hold for files that are not at 22 050 Hz, and
+the product's device-free host code (plan, filter bank, output length: bliss-rs_amd/csrc/resample.hpp through the C ABI)
+against the oracle.
+
+The pins: three Adler-32 values of the decoded f32le stream (ffmpeg.rs:433-445, 471-476) -- the resampler is BIT-pinned on
+44 100 -> 22 050 Hz, mono and stereo, s16 and 24-bit input; with it the three CUE tracks of data/testcue.flac give the
+3 x 23 features src/cue.rs:270-415 asserts and data/tone_11080Hz.flac the centroid / rolloff of src/timbral.rs:364-373, 430-439.
+"""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import cue_bounds, decoded_audio, load_golden
+
+
+def _adler(x):
+    return zlib.adler32(np.ascontiguousarray(x, dtype="<f4").tobytes()) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("name", ["s32_mono_44_1_kHz.flac", "s32_stereo_44_1_kHz.flac", "no_channel.wav"])
+def test_oracle_resampler_adler32(oracle, literals, name):
+    samples, rate = decoded_audio(name)
+    assert rate == 44100
+    got = oracle.decode_to_mono(samples, rate)
+    assert len(got) == (samples.shape[0] + 1) // 2
+    assert _adler(got) == int(literals["resample"]["adler32"][name], 16)
+
+
+def test_oracle_stereo_matrix_at_22050(oracle, literals):
+    # no resampling: only the rematrix l * sqrt(1/2) + r * sqrt(1/2); the same pin as the (L + R) * SQRT_2 / 2 form
+    s = load_golden("s16_stereo_22_5kHz.pcm_s16.npy")
+    assert _adler(oracle.decode_to_mono(s, 22050)) == int(literals["resample"]["adler32"]["s16_stereo_22_5kHz.flac"], 16)
+
+
+def test_oracle_cue_tracks(oracle, literals):
+    # src/cue.rs:270-415 asserts these 3 x 23 values with assert_eq (FFmpegDecoder on the author's machine); the oracle's FFT is
+    # not rustfft, so "equal" is the golden song's 1e-5 here -- measured 3.6e-7, 63 of 69 bit-equal
+    cue = literals["resample"]["cue"]
+    samples, rate = decoded_audio(cue["file"])
+    pcm = oracle.decode_to_mono(samples, rate)
+    assert len(pcm) == 496272
+    worst = 0.0
+    for (a, b), exp in zip(cue_bounds(cue["index_mm_ss_ff"], len(pcm)), cue["tracks"]):
+        got = oracle.song_analyze(pcm[a:b], 2)
+        worst = max(worst, float(np.abs(got - np.array(exp, np.float32)).max()))
+    assert worst < 1e-6, worst
+
+
+def test_oracle_tone_timbral(oracle, literals):
+    t = literals["resample"]["tone_11080Hz"]
+    samples, rate = decoded_audio("tone_11080Hz.flac")
+    pcm = oracle.decode_to_mono(samples, rate)
+    sd = oracle.SpectralDesc()
+    sd.run(pcm, framing="chunks_exact")
+    centroid, rolloff, _ = sd.values()
+    assert np.abs(centroid - np.array(t["centroid"]["values"], np.float32)).max() < t["centroid"]["tol"]
+    assert np.abs(rolloff - np.array(t["rolloff"]["values"], np.float32)).max() < t["rolloff"]["tol"]
+
+
+def test_oracle_symphonia_literals(oracle, literals):
+    # the reference's OTHER decoder (rubato) on the 44.1 kHz stereo twin of the golden song: its own tolerance is 0.1;
+    # FFmpeg's resampler lands within 2e-2 of it
+    t = literals["resample"]["analysis_symphonia_s32_stereo_44_1_kHz"]
+    samples, rate = decoded_audio("s32_stereo_44_1_kHz.flac")
+    got = oracle.song_analyze(oracle.decode_to_mono(samples, rate), 2)
+    assert np.abs(got - np.array(t["values"], np.float32)).max() < t["tol"]
+
+
+def test_oracle_lengths(oracle, literals):
+    samples, rate = decoded_audio("flush_test_52000.wav")
+    assert rate == 48000 and len(oracle.decode_to_mono(samples, rate)) == literals["resample"]["lengths"]["flush_test_52000.wav"]
+    # symphonia.rs:384-402: expected_output_len = ceil(ratio * len), which its test holds equal to FFmpeg's count on the
+    # files above.  libswresample's own rule (outputs while a full window is left in the stream + the mirrored
+    # (min(left, taps) + 1) / 2 samples) gives exactly that for every length at 2 : 1 (the reference's case), and that or one less at
+    # other ratios (the mirrored stretch is a sample shorter when an even number of samples is left)
+    rng = np.random.default_rng(5)
+    for rate in (8000, 11025, 16000, 24000, 32000, 44056, 44100, 48000, 88200, 96000, 176400, 192000):
+        taps = oracle.swr_filter(rate)[1].taps
+        for n in [1000, 8192, 100000] + rng.integers(300, 5_000_000, 6).tolist():
+            exp = -(-n * 22050 // rate)
+            got = oracle.swr_out_len(n, rate)
+            if n <= taps:
+                assert got == 0
+            elif rate == 44100:
+                assert got == exp, (rate, n)
+            else:
+                assert got in (exp, exp - 1), (rate, n)
+    assert oracle.swr_out_len(12345, 22050) == 12345
+
+
+def test_oracle_filter_shape(oracle):
+    bank, p = oracle.swr_filter(44100)
+    assert (p.taps, p.phase_count, p.dst_incr, p.src_incr) == (66, 1, 2, 1)
+    assert abs(float(bank.astype(np.float64).sum()) - 1.0) < 1e-6  # "an uniform color remains the same"
+    bank, p = oracle.swr_filter(48000)
+    assert (p.taps, p.phase_count, p.dst_incr, p.src_incr) == (72, 147, 320, 1)
+    bank, p = oracle.swr_filter(11025)  # up-sampling: no low-pass, 32 taps, two phases, phase 0 passes the sample through
+    assert (p.taps, p.phase_count) == (32, 2)
+    assert bank[0, p.center] == 1.0 and np.count_nonzero(bank[0]) == 1
+    bank, p = oracle.swr_filter(96000)  # even phase_count: upper phases are tap-reversed copies
+    assert p.phase_count == 147
+    bank, p = oracle.swr_filter(22050 * 4 // 3 * 1)  # 29400 Hz: 3 / 4
+    assert p.phase_count == 3
+    bank, p = oracle.swr_filter(25200)  # 7 / 8
+    assert p.phase_count == 7
+    bank, p = oracle.swr_filter(33075)  # 2 / 3: even bank, phase 1 is its own mirror
+    assert p.phase_count == 2 and np.array_equal(bank[1], bank[1][::-1])
+
+
+# ---- the product's device-free host code against the oracle (no GPU needed: plan, bank and count are host arithmetic) ----
+RATES = (8000, 11025, 16000, 24000, 29400, 32000, 33075, 44056, 44100, 48000, 88200, 96000, 176400, 192000, 384000, 768000)
+
+
+def test_library_filter_bank_equals_oracle(oracle):
+    from bliss_rs_amd import _ffi
+
+    L = _ffi.lib()
+    for rate in RATES:
+        taps, pc = C.c_uint32(0), C.c_uint32(0)
+        _ffi.check(L.blissgpu_resample_filter(rate, None, 0, C.byref(taps), C.byref(pc)))
+        ref, p = oracle.swr_filter(rate)
+        assert (taps.value, pc.value) == (p.taps, p.phase_count), rate
+        bank = np.zeros((pc.value, taps.value), np.float32)
+        _ffi.check(L.blissgpu_resample_filter(rate, bank.ctypes.data, bank.size, None, None))
+        assert np.array_equal(bank.view(np.uint32), ref.view(np.uint32)), rate
+    assert L.blissgpu_resample_filter(0, None, 0, None, None) == _ffi.ERR_INVALID
+    assert L.blissgpu_resample_filter(768001, None, 0, None, None) == _ffi.ERR_INVALID
+
+
+def test_library_resampled_len_equals_oracle(oracle):
+    from bliss_rs_amd import _ffi
+
+    L = _ffi.lib()
+    rng = np.random.default_rng(6)
+    for rate in RATES + (22050,):
+        for n in [0, 1, 32, 33, 66, 67, 68, 1000, 8192, 3969000 * 2] + rng.integers(1, 30_000_000, 8).tolist():
+            assert L.blissgpu_resampled_len(n, rate) == oracle.swr_out_len(n, rate), (rate, n)
+    assert L.blissgpu_resampled_len(1000, 0) == 0 and L.blissgpu_resampled_len(1000, 768001) == 0
