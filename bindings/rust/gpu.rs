@@ -14,6 +14,9 @@
 //!                                             src/song/decoder.rs:278-332 -> [`analyze_decoded`] (one device batch), or the
 //!     crate's own worker threads calling [`analyze_with_options`]: concurrent calls are coalesced inside the library and
 //!     spread over every GPU of the node
+//!   * `FFmpegDecoder::resample_frame` (libswresample to mono 22 050 Hz f32)
+//!                                             src/song/decoder/ffmpeg.rs:36-109 -> [`analyze_native`] / [`DecodedPcm`]: the
+//!     decoder hands over the codec's own frames, the conversion runs on the device, bit for bit
 //!   * `PreAnalyzedSong::to_song_with_options` src/song/decoder.rs:85-101  -> unchanged, it calls `Song::analyze_with_options`
 //!   * `euclidean_distance` / `cosine_distance` / `mahalanobis_distance`
 //!                                             src/playlist.rs:65-79,140-142 -> [`distance`], [`pairwise`]
@@ -33,7 +36,7 @@
 use crate::{Analysis, AnalysisOptions, BlissError, BlissResult, FeaturesVersion, Song};
 use ndarray::Array2;
 use std::ffi::CStr;
-use std::os::raw::{c_char, c_int};
+use std::os::raw::{c_char, c_int, c_void};
 
 /// Raw declarations (`include/blissgpu.h`).
 pub mod sys {
@@ -63,6 +66,19 @@ pub mod sys {
     pub const BLISSGPU_METRIC_MAHALANOBIS: c_int = 2;
     pub const BLISSGPU_SAMPLE_F32: c_int = 0;
     pub const BLISSGPU_SAMPLE_S16: c_int = 1;
+    pub const BLISSGPU_SAMPLE_S32: c_int = 2;
+    pub const BLISSGPU_SAMPLE_RATE: u32 = 22050;
+
+    /// One song as the decoder delivers it (host memory): `frames` frames of `channels` interleaved samples.
+    #[repr(C)]
+    #[derive(Clone, Copy)]
+    pub struct blissgpu_decoded_song {
+        pub pcm: *const c_void,
+        pub frames: u64,
+        pub sample_rate: u32,
+        pub channels: u16,
+        pub sample_format: u16,
+    }
 
     extern "C" {
         // ---- contexts ----
@@ -88,6 +104,12 @@ pub mod sys {
         pub fn blissgpu_analyze_batch_interleaved(pcm: *const c_void, sample_format: c_int, channels: u32,
                                                   offsets: *const u64, lengths: *const u64, n_songs: u32,
                                                   features_version: u32, out: *mut f32, status: *mut i32) -> c_int;
+        pub fn blissgpu_analyze_decoded(pcm: *const c_void, sample_format: c_int, channels: u32, frames: u64, sample_rate: u32,
+                                        features_version: u32, out: *mut f32, status: *mut i32) -> c_int;
+        pub fn blissgpu_analyze_batch_decoded(songs: *const blissgpu_decoded_song, n_songs: u32, features_version: u32,
+                                              out: *mut f32, status: *mut i32) -> c_int;
+        pub fn blissgpu_resampled_len(frames: u64, sample_rate: u32) -> u64;
+        pub fn blissgpu_default_reset() -> c_int;
         pub fn blissgpu_analyze_batch_device(ctx: *mut blissgpu_ctx, d_pcm: *const f32, offsets: *const u64,
                                              lengths: *const u64, n_songs: u32, features_version: u32, d_out: *mut f32,
                                              d_status: *mut i32) -> c_int;
@@ -176,22 +198,49 @@ impl Song {
 
 /// Bulk form for `Decoder::analyze_paths_with_options`: decode on the CPU workers as today, then hand the decoded buffers
 /// over in ONE call instead of analysing per thread (src/song/decoder.rs:304-328).  The library orders the songs by
-/// length, cuts them into chunks that fit its workspace and streams the PCM over PCIe group by group.
+/// length, cuts them into chunks that fit its workspace and streams the PCM over PCIe group by group -- straight from
+/// the callers' buffers: nothing is copied on the host.
 pub fn analyze_decoded(songs: &[&[f32]], version: FeaturesVersion) -> BlissResult<Vec<BlissResult<Analysis>>> {
-    let d = version.feature_count();
-    let lengths: Vec<u64> = songs.iter().map(|s| s.len() as u64).collect();
-    let mut offsets = Vec::with_capacity(songs.len());
-    let mut pcm: Vec<f32> = Vec::with_capacity(lengths.iter().sum::<u64>() as usize);
-    for s in songs {
-        offsets.push(pcm.len() as u64);
-        pcm.extend_from_slice(s);
+    let native: Vec<DecodedPcm> = songs.iter().map(|s| DecodedPcm::F32 { samples: s, channels: 1, sample_rate: sys::BLISSGPU_SAMPLE_RATE }).collect();
+    analyze_native(&native, version)
+}
+
+/// What a decoder delivers BEFORE the conversion `FFmpegDecoder::resample_frame` does (src/song/decoder/ffmpeg.rs:36-109):
+/// interleaved frames at the file's own rate.  The library converts to mono 22 050 Hz f32 on the device exactly as
+/// libswresample does with the decoder's options -- same filter, same summation order; the reference's Adler-32 decoder
+/// tests (ffmpeg.rs:433-452) hold for its output -- so a decoder built on this skips `resample_frame` altogether.
+#[derive(Clone, Copy)]
+pub enum DecodedPcm<'a> {
+    F32 { samples: &'a [f32], channels: u16, sample_rate: u32 },
+    S16 { samples: &'a [i16], channels: u16, sample_rate: u32 },
+    /// FFmpeg's AV_SAMPLE_FMT_S32 (24-bit streams arrive left-justified)
+    S32 { samples: &'a [i32], channels: u16, sample_rate: u32 },
+}
+
+impl<'a> DecodedPcm<'a> {
+    fn raw(&self) -> sys::blissgpu_decoded_song {
+        let (pcm, len, channels, sample_rate, fmt) = match *self {
+            DecodedPcm::F32 { samples, channels, sample_rate } => (samples.as_ptr() as *const c_void, samples.len(), channels, sample_rate, sys::BLISSGPU_SAMPLE_F32),
+            DecodedPcm::S16 { samples, channels, sample_rate } => (samples.as_ptr() as *const c_void, samples.len(), channels, sample_rate, sys::BLISSGPU_SAMPLE_S16),
+            DecodedPcm::S32 { samples, channels, sample_rate } => (samples.as_ptr() as *const c_void, samples.len(), channels, sample_rate, sys::BLISSGPU_SAMPLE_S32),
+        };
+        sys::blissgpu_decoded_song { pcm, frames: (len / channels.max(1) as usize) as u64, sample_rate, channels, sample_format: fmt as u16 }
     }
+    /// Samples at 22 050 Hz this song becomes (`PreAnalyzedSong::duration`, src/song/decoder.rs:34-65).
+    pub fn resampled_len(&self) -> u64 {
+        let r = self.raw();
+        unsafe { sys::blissgpu_resampled_len(r.frames, r.sample_rate) }
+    }
+}
+
+/// `analyze_paths_with_options` for decoders that keep the file's format: a library of 44.1 / 48 kHz, mono / stereo, 16 /
+/// 24-bit files in one call (blissgpu_analyze_batch_decoded).
+pub fn analyze_native(songs: &[DecodedPcm], version: FeaturesVersion) -> BlissResult<Vec<BlissResult<Analysis>>> {
+    let d = version.feature_count();
+    let raw: Vec<sys::blissgpu_decoded_song> = songs.iter().map(|s| s.raw()).collect();
     let mut out = vec![0f32; songs.len() * d];
     let mut status = vec![0i32; songs.len()];
-    let rc = unsafe {
-        sys::blissgpu_analyze_batch(pcm.as_ptr(), offsets.as_ptr(), lengths.as_ptr(), songs.len() as u32, version_code(version),
-                                    out.as_mut_ptr(), status.as_mut_ptr())
-    };
+    let rc = unsafe { sys::blissgpu_analyze_batch_decoded(raw.as_ptr(), raw.len() as u32, version_code(version), out.as_mut_ptr(), status.as_mut_ptr()) };
     if rc != sys::BLISSGPU_OK {
         return Err(gpu_err(rc));
     }

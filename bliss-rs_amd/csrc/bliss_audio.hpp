@@ -208,8 +208,48 @@ struct Song {
         if (status != BLISSGPU_SONG_OK) throw AnalysisError("empty or too short song.");
         return Analysis(std::move(out), opt.features_version);
     }
+    // Decoder output at ANY sample rate (`channels` interleaved channels of f32 / s16 / s32): what FFmpegDecoder::decode does
+    // before Song::analyze -- libswresample to mono 22 050 Hz, src/song/decoder/ffmpeg.rs:36-109 -- runs on the device,
+    // bit for bit (pinned by the reference's Adler-32 decoder tests, ffmpeg.rs:433-452).
+    static Analysis analyze_decoded(const std::vector<float>& samples, uint32_t channels, uint32_t sample_rate, const AnalysisOptions& opt = {}) {
+        return analyze_decoded_raw(samples.data(), BLISSGPU_SAMPLE_F32, channels, samples.size() / (channels ? channels : 1), sample_rate, opt);
+    }
+    static Analysis analyze_decoded(const std::vector<int16_t>& samples, uint32_t channels, uint32_t sample_rate, const AnalysisOptions& opt = {}) {
+        return analyze_decoded_raw(samples.data(), BLISSGPU_SAMPLE_S16, channels, samples.size() / (channels ? channels : 1), sample_rate, opt);
+    }
+    static Analysis analyze_decoded(const std::vector<int32_t>& samples, uint32_t channels, uint32_t sample_rate, const AnalysisOptions& opt = {}) {
+        return analyze_decoded_raw(samples.data(), BLISSGPU_SAMPLE_S32, channels, samples.size() / (channels ? channels : 1), sample_rate, opt);
+    }
+    static Analysis analyze_decoded_raw(const void* pcm, int sample_format, uint32_t channels, uint64_t frames, uint32_t sample_rate,
+                                        const AnalysisOptions& opt) {
+        std::vector<float> out(feature_count(opt.features_version));
+        int32_t status = 0;
+        const float dummy = 0.0f;
+        check(blissgpu_analyze_decoded(frames ? pcm : &dummy, sample_format, channels, frames, sample_rate,
+                                       static_cast<uint32_t>(opt.features_version), out.data(), &status));
+        if (status != BLISSGPU_SONG_OK) throw AnalysisError("empty or too short song.");
+        return Analysis(std::move(out), opt.features_version);
+    }
     float distance(const Song& other) const { return analysis.distance(other.analysis); }
 };
+
+// Bulk form for a library as it comes off the decoders: every song with its own buffer, format, channel count and rate
+// (blissgpu_analyze_batch_decoded); the compute half of analyze_paths_with_options (src/song/decoder.rs:278-332) for a host
+// that keeps its decoder and drops the resampler.
+inline std::vector<BlissResult<Analysis>> analyze_decoded_batch(const std::vector<blissgpu_decoded_song>& songs, const AnalysisOptions& opt = {}) {
+    const uint32_t n = static_cast<uint32_t>(songs.size());
+    const size_t d = feature_count(opt.features_version);
+    std::vector<float> out(n * d);
+    std::vector<int32_t> status(n);
+    if (n) check(blissgpu_analyze_batch_decoded(songs.data(), n, static_cast<uint32_t>(opt.features_version), out.data(), status.data()));
+    std::vector<BlissResult<Analysis>> res;
+    res.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (status[i] == BLISSGPU_SONG_OK) res.emplace_back(Analysis(std::vector<float>(out.begin() + i * d, out.begin() + (i + 1) * d), opt.features_version));
+        else res.emplace_back(AnalysisError("empty or too short song."));
+    }
+    return res;
+}
 
 // ---- Decoder trait (src/song/decoder.rs:34-333) ----
 struct PreAnalyzedSong {

@@ -902,13 +902,14 @@ int blissgpu_resample_filter(uint32_t sample_rate, float* bank, uint64_t max_ele
 int blissgpu_pcm_decode_device(blissgpu_ctx* c, const void* d_in, int sample_format, uint32_t channels, uint64_t frames,
                                uint32_t sample_rate, float* d_out) {
     const char* who = "blissgpu_pcm_decode_device";
-    if (!c || (frames && (!d_in || !d_out))) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
     if (!known_format(sample_format) || channels == 0 || channels > 8) return fail(BLISSGPU_ERR_INVALID, who, "bad sample_format / channels");
     if (sample_rate == 0 || sample_rate > bg::MAX_SAMPLE_RATE) return fail(BLISSGPU_ERR_INVALID, who, "sample_rate must be 1 .. 768000 Hz");
+    const uint64_t n_out = blissgpu_resampled_len(frames, sample_rate);
+    if (!c || (n_out && (!d_in || !d_out))) return fail(BLISSGPU_ERR_INVALID, who, "NULL argument");
+    if (n_out == 0) return BLISSGPU_OK;  // a stream shorter than the resampler's start-up converts to nothing
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    return bg::enqueue_decode(c, d_in, sample_format, channels, frames, sample_rate, d_out, blissgpu_resampled_len(frames, sample_rate),
-                              c->stream, who);
+    return bg::enqueue_decode(c, d_in, sample_format, channels, frames, sample_rate, d_out, n_out, c->stream, who);
 }
 
 }  // extern "C"

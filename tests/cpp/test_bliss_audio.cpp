@@ -1,6 +1,6 @@
 // C++ host-mirror test: reads like the reference's own unit tests (src/song/mod.rs:539-633,
 // src/playlist.rs:1008-1110, src/lib.rs:272-291) but runs on the GPU through libblissgpu.so.
-//   usage: test_bliss_audio <golden pcm s16 raw file> <expected 23 floats file>
+//   usage: test_bliss_audio <golden pcm s16 raw file> <expected 23 floats file> [<stereo s16 raw> [<44.1 kHz stereo s32 raw> <its 23 floats>]]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,7 +29,7 @@ struct RawS16Decoder : Decoder {  // ffmpeg's s16 -> flt conversion: sample / 32
 };
 
 int main(int argc, char** argv) {
-    CHECK(argc == 3 || argc == 4);
+    CHECK(argc == 3 || argc == 4 || argc == 6);
     // test_analysis_too_small (src/song/mod.rs:539-551)
     try { Song::analyze({0.0f}); CHECK(false); } catch (const BlissError& e) { CHECK(e == AnalysisError("empty or too short song.")); }
     try { Song::analyze({}); CHECK(false); } catch (const BlissError& e) { CHECK(e == AnalysisError("empty or too short song.")); }
@@ -66,6 +66,25 @@ int main(int argc, char** argv) {
             mono[i] = scaled / 2.0f;
         }
         CHECK(Song::analyze_interleaved(st, 2) == Song::analyze(mono));
+    }
+    // decoder output at another rate (44.1 kHz stereo, 24-bit samples in s32): FFmpegDecoder's conversion runs on the device
+    // (src/song/decoder/ffmpeg.rs:36-109); argv[5] holds the row the Python mirror got from the same call
+    if (argc == 6) {
+        std::ifstream f(argv[4], std::ios::binary);
+        std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        std::vector<int32_t> st(raw.size() / 4);
+        std::memcpy(st.data(), raw.data(), st.size() * 4);
+        std::vector<float> want(23);
+        { std::ifstream g(argv[5]); for (auto& v : want) g >> v; }
+        const Analysis got = Song::analyze_decoded(st, 2, 44100);
+        for (size_t i = 0; i < 23; i++) CHECK(got.as_vec()[i] == want[i]);
+        CHECK(blissgpu_resampled_len(st.size() / 2, 44100) == (st.size() / 2 + 1) / 2);
+        // the bulk form with two different songs of the same file: the row above, and a too-short one
+        std::vector<blissgpu_decoded_song> lib = {{st.data(), st.size() / 2, 44100, 2, BLISSGPU_SAMPLE_S32},
+                                                  {st.data(), 1000, 48000, 2, BLISSGPU_SAMPLE_S32}};
+        auto r = analyze_decoded_batch(lib);
+        CHECK(std::get<Analysis>(r[0]) == got);
+        CHECK(std::get<BlissError>(r[1]) == AnalysisError("empty or too short song."));
     }
     // bulk path: a missing file is reported, not fatal (src/song/decoder.rs:313-325)
     auto res = dec.analyze_paths({argv[1], "/nonexistent.raw"});

@@ -622,6 +622,17 @@ def test_cpp_host_mirror(tmp_path, literals):
     exp.write_text(" ".join(repr(v) for v in literals["analysis_v2_s16_mono_22_5kHz"]["values"]))
     stereo = tmp_path / "stereo.s16"
     load_golden("s16_stereo_22_5kHz.pcm_s16.npy").astype("<i2").tofile(stereo)
-    out = subprocess.run([str(exe), str(raw), str(exp), str(stereo)], capture_output=True, text=True, timeout=300)
+    # decoder output at 44.1 kHz (row f1's resampler through the C++ mirror): the row the Python mirror gets, bit for bit
+    from conftest import decoded_audio
+    import bliss_rs_amd as bliss
+
+    s44, rate = decoded_audio("s32_stereo_44_1_kHz.flac")
+    assert rate == 44100 and s44.dtype == np.int32
+    raw44 = tmp_path / "stereo44.s32"
+    s44.astype("<i4").tofile(raw44)
+    exp44 = tmp_path / "expected44.txt"
+    exp44.write_text(" ".join("%.9g" % v for v in bliss.Song.analyze_decoded(s44, rate).as_arr1()))
+    out = subprocess.run([str(exe), str(raw), str(exp), str(stereo), str(raw44), str(exp44)], capture_output=True, text=True,
+                         timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout

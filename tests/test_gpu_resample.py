@@ -44,7 +44,7 @@ def _adler(x):
 def _decode(ctx, samples, rate):
     import torch
 
-    out = ctx.pcm_decode(torch.from_numpy(np.ascontiguousarray(samples)).cuda(), rate)
+    out = ctx.pcm_decode(torch.from_numpy(np.array(samples)).cuda(), rate)
     ctx.synchronize()
     return out.cpu().numpy()
 
@@ -104,7 +104,7 @@ def test_cue_tracks_through_the_device(bliss, ctx, oracle, literals):
 
     cue = literals["resample"]["cue"]
     samples, rate = decoded_audio(cue["file"])
-    pcm = ctx.pcm_decode(torch.from_numpy(samples).cuda(), rate)
+    pcm = ctx.pcm_decode(torch.from_numpy(np.array(samples)).cuda(), rate)
     assert pcm.numel() == 496272
     bounds = cue_bounds(cue["index_mm_ss_ff"], pcm.numel())
     out, status = ctx.analyze(pcm, [a for a, _ in bounds], [b - a for a, b in bounds], 2)

@@ -413,7 +413,8 @@ def test_rust_binding_declarations_match_the_header():
         t = re.sub(r"\s+[A-Za-z_][A-Za-z_0-9]*$", "", t) if not t.endswith("*") and len(t.split()) > 1 and t.split()[-1] not in (
             "int", "float", "double", "char", "void", "uint64_t", "uint32_t", "int64_t", "int32_t", "int16_t") else t
         base = {"int": "c_int", "float": "f32", "double": "f64", "uint64_t": "u64", "uint32_t": "u32", "int64_t": "i64", "int32_t": "i32",
-                "int16_t": "i16", "void": "c_void", "char": "c_char", "blissgpu_ctx": "blissgpu_ctx", "blissgpu_node": "blissgpu_node"}
+                "int16_t": "i16", "void": "c_void", "char": "c_char", "blissgpu_ctx": "blissgpu_ctx", "blissgpu_node": "blissgpu_node",
+                "blissgpu_decoded_song": "blissgpu_decoded_song"}
         toks = t.split()
         const = toks[0] == "const"
         if const:
