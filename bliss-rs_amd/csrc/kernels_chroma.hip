@@ -771,7 +771,10 @@ __global__ __launch_bounds__(256) void tune_pass2_kernel(const SongDesc* __restr
     for (int i = 0; i < P2_FRAMES_PER_WAVE; i++) {
         const uint32_t f = tile * CH_TILE + wave + 4 * i;
         if (f >= sd.n_c) break;  // wave-uniform
-        const uint32_t n_rec = n_rec_next;
+        // (a frame holds at most PIP_MAX_PER_FRAME records -- two neighbouring bins cannot both be peaks; the clamp costs one
+        // instruction per frame and keeps a count that was never written, should a future change leave one, from walking off
+        // the record row)
+        const uint32_t n_rec = n_rec_next < (uint32_t)PIP_MAX_PER_FRAME ? n_rec_next : (uint32_t)PIP_MAX_PER_FRAME;
         if (i + 1 < P2_FRAMES_PER_WAVE && f + 4 < sd.n_c) n_rec_next = peak_cnt[sd.c_off + f + 4];
         const uint32_t* __restrict__ recs = peak_rec + (sd.c_off + f) * (size_t)PIP_MAX_PER_FRAME;
         if (n_slow + PIP_MAX_PER_FRAME > P2_SLOW_CAP) flush();  // wave-uniform
@@ -923,7 +926,8 @@ __global__ __launch_bounds__(256) void tune_final_kernel(const SongDesc* __restr
             }
         } else {
             for (uint32_t f = 0; f < sd.n_c; f++) {
-                const uint32_t n_rec = peak_cnt[sd.c_off + f];
+                const uint32_t n_rec_raw = peak_cnt[sd.c_off + f];
+                const uint32_t n_rec = n_rec_raw < (uint32_t)PIP_MAX_PER_FRAME ? n_rec_raw : (uint32_t)PIP_MAX_PER_FRAME;
                 const uint32_t* __restrict__ recs = peak_rec + (sd.c_off + f) * (size_t)PIP_MAX_PER_FRAME;
                 const float* __restrict__ row = spec + (sd.c_off + f) * (size_t)CBINS_PAD;
                 const double ref = 0.1 * (double)frame_max[sd.c_off + f];
