@@ -150,6 +150,17 @@ def main():
                          -0.9269961, 0.7498772, 0.22429907, 0.9990841, -0.9723601, -0.973079, -0.97307926,
                          -0.97308147, -0.9730794, -2.783537e-5, -2.7775764e-5, 3.1113625e-5, 2.4557114e-5,
                          -0.9210111, -0.99999785, -0.99993163]]},
+            "cue_v1": {"src": "src/cue.rs:417-523 (test_cue_analysis_with_options: FeaturesVersion::Version1 on the same tracks)",
+                       "tracks": [
+                           [0.38463724, -0.85219246, -0.761946, -0.8904667, -0.63892543, -0.73945934, -0.80040205,
+                            -0.82372904, 0.33865356, 0.32481194, -0.35692245, -0.6355889, -0.29584837, 0.06431806,
+                            0.21875131, -0.58104205, -0.9466792, -0.94811195, -0.9820919, -0.9596871],
+                           [0.18622077, -0.5989029, -0.5554645, -0.63438654, -0.24163479, -0.25766593, -0.40616918,
+                            -0.23334831, 0.76875293, 0.7785741, -0.5075115, -0.5272629, -0.56706166, -0.568486,
+                            -0.5639081, -0.5706943, -0.96501005, -0.96501285, -0.9649896, -0.96498996],
+                           [0.0024260283, 0.9874661, 0.97330654, -0.97244257, 0.99678576, -0.9961549, -0.98401415,
+                            -0.9269961, 0.7498772, 0.22429907, -0.8355152, -0.9977258, -0.9977849, -0.997785,
+                            -0.99778515, -0.997785, -0.99999976, -0.99999976, -0.99999976, -0.99999976]]},
             "tone_11080Hz": {"_note": "SpectralDesc over chunks_exact(HOP_SIZE) of the decoded (resampled) file",
                              "centroid": {"src": "src/timbral.rs:430-439", "tol": 1e-5, "values": [0.97266, -0.9609926]},
                              "rolloff": {"src": "src/timbral.rs:364-373", "tol": 1e-4, "values": [0.9967681, -0.99615175]}},

@@ -133,6 +133,18 @@ def test_cue_tracks_through_the_device(bliss, ctx, oracle, literals):
         assert (d_ref <= tol + 4e-7).all(), (t, d_ref)  # + the oracle's own distance from the literals (3.6e-7)
 
 
+    # FeaturesVersion::Version1 on the same slices (src/cue.rs:417-523): 3 x 20 literals
+    out1, status1 = ctx.analyze(pcm, [a for a, _ in bounds], [b - a for a, b in bounds], 1)
+    ctx.synchronize()
+    rows1 = out1.cpu().numpy()
+    assert rows1.shape == (3, 20) and status1.cpu().tolist() == [0, 0, 0]
+    for row, exp in zip(rows1, literals["resample"]["cue_v1"]["tracks"]):
+        d = np.abs(row - np.array(exp, np.float32))
+        assert d[10:].max() < FEATURE_TOL, d  # the ten Version1 chroma features
+    # (the first ten features are the same computation in both versions -- and the same literals: held above)
+    assert np.array_equal(rows1[:, :10], rows[:, :10])
+
+
 def test_analyze_decoded_single_song(bliss, oracle, literals):
     # Song::analyze on FFmpegDecoder's output for the 44.1 kHz stereo twin of the golden song, through the single-song front
     samples, rate = decoded_audio("s32_stereo_44_1_kHz.flac")

@@ -47,6 +47,13 @@ def test_oracle_cue_tracks(oracle, literals):
         got = oracle.song_analyze(pcm[a:b], 2)
         worst = max(worst, float(np.abs(got - np.array(exp, np.float32)).max()))
     assert worst < 1e-6, worst
+    # the same tracks with FeaturesVersion::Version1 (src/cue.rs:417-523): 3 x 20
+    worst = 0.0
+    for (a, b), exp in zip(cue_bounds(cue["index_mm_ss_ff"], len(pcm)), literals["resample"]["cue_v1"]["tracks"]):
+        got = oracle.song_analyze(pcm[a:b], 1)
+        assert got.shape == (20,)
+        worst = max(worst, float(np.abs(got - np.array(exp, np.float32)).max()))
+    assert worst < 1e-6, worst
 
 
 def test_oracle_tone_timbral(oracle, literals):
