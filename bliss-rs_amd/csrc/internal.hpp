@@ -180,7 +180,7 @@ void launch_fft512(const Batch&, const Workspace&, const DeviceTables&, hipStrea
 void launch_rolloff_fix(const Batch&, const Workspace&, uint64_t total_t, hipStream_t);
 void launch_onset(const Batch&, const Workspace&, hipStream_t);
 void launch_beat(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
-void launch_stft8192(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
+void launch_stft8192(const Batch&, const Workspace&, const DeviceTables&, hipStream_t, int shape = 0);  // shape: BLISSGPU_OPT_STFT_SHAPE
 // a contiguous range of a chunk's songs [s0, s1) with the tile / workgroup ranges that belong to it in pfx_ct / pfx_cw
 // units (the tuning estimate and the contraction of a one-chunk batch run in two halves; NULL = the whole chunk)
 struct SongRange { uint32_t s0, s1, ct0, ct1, cw0, cw1; };

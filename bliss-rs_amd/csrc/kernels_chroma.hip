@@ -289,8 +289,16 @@ __device__ __forceinline__ long reflect_index(long p, long n) {
 #define TRACE_FLUSH() do {} while (0)
 #endif
 
-// 4 workgroups per CU: 128 VGPRs, spill-free
-__global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restrict__ pcm,
+// NARROW = false (production): 4 workgroups per CU at 128 VGPRs / 40.4 KB LDS, spill-free, the window in registers.
+// NARROW = true (BLISSGPU_OPT_STFT_SHAPE = 1; the "other shape" of the round-4 review, built in round 5 for the A/B): 5
+// workgroups per CU -- <= 96 VGPRs and 23 KB LDS.  What has to give: the window leaves the registers and is loaded with
+// every frame's samples (16 more vector-memory loads per frame-thread); the two transposes go through a 17 KB float buffer
+// in two halves (re, then im: twice the LDS instructions and four more barriers per frame); the magnitude row can no longer
+// hide in a dead half of the exchange buffer (one more barrier).  Same arithmetic, same operands: rows bit-identical.
+constexpr int STFT_LDS_N = 16 * EX2_PITCH;  // floats (17 408 B): 16 rows of 272 floats >= the 4128-float magnitude row
+constexpr int EXN1_PITCH = 260;             // floats; == 4 (mod 32): the 64 readers of pass 2 fall two to a bank
+template <bool LOADWIN, bool HALVES>  // NARROW = both; one alone is a measurement form (shapes 2 and 3)
+__global__ __launch_bounds__(256, (LOADWIN && HALVES) ? 5 : 4) void stft8192_kernel(const float* __restrict__ pcm,
                                                        const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                        const uint32_t* __restrict__ pfx_c,
                                                        const float* __restrict__ hann,
@@ -299,7 +307,11 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
                                                        float* __restrict__ frame_max, uint32_t* __restrict__ h1,
                                                        uint32_t* __restrict__ peak_rec, uint32_t* __restrict__ peak_cnt,
                                                        uint32_t n_tiles) {
-    __shared__ f2 lds[STFT_LDS];
+    constexpr bool NARROW = HALVES;  // the LDS layout follows the transposes
+    __shared__ __attribute__((aligned(16))) float lds_raw[NARROW ? STFT_LDS_N : 2 * STFT_LDS];
+    f2* const lds = reinterpret_cast<f2*>(lds_raw);
+    float* const ldsf = lds_raw;
+    constexpr int MAGS_TOP_W = NARROW ? 4096 : MAGS_TOP;  // word index of magnitude word 4096 (narrow: the row is contiguous)
     __shared__ float red[4];
     // peaks are first counted in an LDS window of the coarse-magnitude histogram (a frame's peaks lie
     // within [0.1 max, ~max], i.e. ~220 coarse bins) and flushed once per workgroup: global atomics on
@@ -341,9 +353,11 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
 
     const uint32_t t8 = 8u * (uint32_t)t;  // byte offset of (x[2t], x[2t+1]) / (hann[2t], hann[2t+1])
     // the window values of this thread's 16 complex inputs stay in registers for all frames of the tile
-    f2 win[16];
+    f2 win[16];  // (LOADWIN: fetched per frame, see load_window)
+    if constexpr (!LOADWIN) {
 #pragma unroll
-    for (int n1 = 0; n1 < 16; n1++) win[n1] = buf_load_f2(r_hann, t8, 2048u * n1);
+        for (int n1 = 0; n1 < 16; n1++) win[n1] = buf_load_f2(r_hann, t8, 2048u * n1);
+    }
     // Twiddles come from a 256-entry LDS table and two per-thread constants instead of per-frame loads of
     // 4096- and 2048-entry tables (every vector-memory load in the frame loop costs an in-order vmcnt wait):
     //   pass 1:  W_4096^((16 m1 + m2) k1) = W_256^(m1 k1) * W_4096^(m2 k1); the second factor does not depend
@@ -374,6 +388,14 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         return (k & 1) ? mk(pair.z, pair.w) : mk(pair.x, pair.y);
     };
     // raw samples of one frame: z[256*n1 + t] = (x[w0 + 2n], x[w0 + 2n + 1]), reflect only at the song edges
+    // LOADWIN: the window is fetched (L1 / L2 hits) right in front of the multiply that consumes it -- requested with the
+    // samples, or ahead of the peak classification, it is spilled across the peak phase (32 registers, measured)
+    auto load_window = [&]() {
+        if constexpr (LOADWIN) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) win[n1] = buf_load_f2(r_hann, t8, 2048u * n1);
+        }
+    };
     auto load_frame = [&](uint32_t f, f2 (&xr)[16]) {
         const long w0 = (long)f * HOP_C - W8192 / 2;
         if (w0 >= 0 && w0 + W8192 <= n) {
@@ -405,6 +427,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
     // stores"; at the loop head the prologue path (no stores) would force a full vmcnt(0) drain per frame.
     if (f_first < sd.n_c) {
         load_frame(f_first, v);
+        load_window();
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window (src/utils.rs:37-39, :49)
     }
@@ -418,6 +441,23 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
 #pragma unroll
         for (int k1 = 1; k1 < 16; k1++)
             v[R16(k1)] = cmul_pk(v[R16(k1)], tw_at(hi4, k1));
+        if constexpr (NARROW) {
+            // the transpose in two halves through the float buffer: real parts, then imaginary parts
+            f2 u[16];
+#pragma unroll
+            for (int k1 = 0; k1 < 16; k1++) ldsf[k1 * EXN1_PITCH + t] = v[R16(k1)].x;
+            __syncthreads();
+#pragma unroll
+            for (int m1 = 0; m1 < 16; m1++) u[m1].x = ldsf[lo4 * EXN1_PITCH + 16 * m1 + hi4];
+            __syncthreads();
+#pragma unroll
+            for (int k1 = 0; k1 < 16; k1++) ldsf[k1 * EXN1_PITCH + t] = v[R16(k1)].y;
+            __syncthreads();
+#pragma unroll
+            for (int m1 = 0; m1 < 16; m1++) u[m1].y = ldsf[lo4 * EXN1_PITCH + 16 * m1 + hi4];
+#pragma unroll
+            for (int m1 = 0; m1 < 16; m1++) v[m1] = u[m1];
+        } else {
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) lds[k1 * EX1_PITCH + t] = v[R16(k1)];
         TRACE(0);
@@ -426,6 +466,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         // ---- pass 2: thread (k1 = lo4, m2 = hi4): DFT over m1; twiddle W_4096^(m2 k1) * W_256^(m2 j1) ----
 #pragma unroll
         for (int m1 = 0; m1 < 16; m1++) v[m1] = lds[lo4 * EX1_PITCH + 16 * m1 + hi4];
+        }
         radix16(v);
         v[R16(0)] = cmul_pk(v[R16(0)], c_p2);
 #pragma unroll
@@ -433,6 +474,22 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         TRACE(2);
         __syncthreads();
         TRACE(3);
+        if constexpr (NARROW) {
+            f2 u[16];
+#pragma unroll
+            for (int j1 = 0; j1 < 16; j1++) ldsf[j1 * EX2_PITCH + t] = v[R16(j1)].x;
+            __syncthreads();
+#pragma unroll
+            for (int m2 = 0; m2 < 16; m2++) u[m2].x = ldsf[hi4 * EX2_PITCH + 16 * m2 + lo4];
+            __syncthreads();
+#pragma unroll
+            for (int j1 = 0; j1 < 16; j1++) ldsf[j1 * EX2_PITCH + t] = v[R16(j1)].y;
+            __syncthreads();
+#pragma unroll
+            for (int m2 = 0; m2 < 16; m2++) u[m2].y = ldsf[hi4 * EX2_PITCH + 16 * m2 + lo4];
+#pragma unroll
+            for (int m2 = 0; m2 < 16; m2++) v[m2] = u[m2];
+        } else {
 #pragma unroll
         for (int j1 = 0; j1 < 16; j1++) lds[j1 * EX2_PITCH + t] = v[R16(j1)];  // = j1*272 + m2*16 + k1
         TRACE(4);
@@ -441,13 +498,15 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         // ---- pass 3: thread (k1 = lo4, j1 = hi4): DFT over m2 -> Z[t + 256*j2] ----
 #pragma unroll
         for (int m2 = 0; m2 < 16; m2++) v[m2] = lds[hi4 * EX2_PITCH + 16 * m2 + lo4];
+        }
         radix16(v);
         TRACE(6);
         __syncthreads();
         TRACE(7);
         // only the upper half (bins 2049..4095, the mirrors of this workgroup's bins 1..2047) is ever read back
+        constexpr int ZOFF = NARROW ? 2048 : 0;  // narrow: Z[k], k >= 2048, lives at complex slot k - 2048 (16 KB in all)
 #pragma unroll
-        for (int j2 = 8; j2 < 16; j2++) lds[t + 256 * j2] = v[R16(j2)];
+        for (int j2 = 8; j2 < 16; j2++) lds[t + 256 * j2 - ZOFF] = v[R16(j2)];
         TRACE(8);
         __syncthreads();
         TRACE(9);
@@ -463,7 +522,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
             float sq_k, sq_m;
             const f2 w = j == 0 ? c_sp : cmul_pk_s(c_sp, mk(CJ, -SJ));
             // k = 0 pairs DC with itself (thread 0's own register); every other mirror is in the upper half
-            const f2 zm = lds[k == 0 ? 2048 : 4096 - k];
+            const f2 zm = lds[(k == 0 ? 2048 : 4096 - k) - ZOFF];
             split_pair_sq(v[R16(j)], (j == 0 && t == 0) ? v[R16(0)] : zm, w, sq_k, sq_m);
             m_lo[j] = mag_from_sq(sq_k);
             m_hi[j] = mag_from_sq(sq_m);
@@ -479,8 +538,9 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         // The split only reads the UPPER half of the exchange buffer (complex slots 2049..4095 = bytes 16 392..32 767);
         // the row of 4128 magnitudes goes into the dead lower half (words 0..4095) and, for bin 4096 and the zero padding,
         // into the 2 KB behind the upper half -- no barrier between the split reads and these writes.
+        if constexpr (NARROW) __syncthreads();  // the row overwrites the mirrored half of Z: every split read must be done
         float* mags = reinterpret_cast<float*>(lds);
-        float* mags_top = mags + MAGS_TOP - 4096;  // mags_top[4096 + i] = word MAGS_TOP + i
+        float* mags_top = mags + MAGS_TOP_W - 4096;  // mags_top[4096 + i] = word MAGS_TOP_W + i
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             mags[t + 256 * j] = m_lo[j];
@@ -511,7 +571,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
             for (int i = 0; i < 5; i++) {
                 const int q = t + 256 * i;
                 if (i < 4 || q < CBINS_PAD / 4) {
-                    const u32x4_t val = i < 4 ? mags4[q] : mags4[q - 1024 + MAGS_TOP / 4];
+                    const u32x4_t val = i < 4 ? mags4[q] : mags4[q - 1024 + MAGS_TOP_W / 4];
                     __builtin_amdgcn_raw_buffer_store_b128(val, r_row, 16u * (uint32_t)q, 0, 2);  // nt: streamed once
                 }
             }
@@ -590,6 +650,7 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
         }
         __builtin_amdgcn_s_setprio(0);
         if (has_next) {
+            load_window();
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) v[n1] = v[n1] * win[n1];  // window of the next frame
         }
@@ -609,10 +670,15 @@ __global__ __launch_bounds__(256, 4) void stft8192_kernel(const float* __restric
     }
 }
 
-void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
+void launch_stft8192(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st, int shape) {
     if (b.tiles_c == 0) return;
-    hipLaunchKernelGGL(stft8192_kernel, dim3((b.tiles_c + 31u) & ~31u), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_c,
-                       t.hann8192, t.tw8192, w.spec, w.frame_max, w.h1, w.peak_rec, w.peak_cnt, b.tiles_c);
+    auto k = stft8192_kernel<false, false>;
+    if (shape == 1) k = stft8192_kernel<true, true>;
+    else if (shape == 2) k = stft8192_kernel<true, false>;   // measurement forms: the window loaded per frame only,
+    else if (shape == 3) k = stft8192_kernel<false, true>;   // the transposes in two halves only (both at 4 workgroups / CU)
+    hipLaunchKernelGGL(k, dim3((b.tiles_c + 31u) & ~31u), dim3(256), 0, st,
+                       b.pcm, b.songs, b.n_songs, b.pfx_c, t.hann8192, t.tw8192, w.spec, w.frame_max, w.h1, w.peak_rec, w.peak_cnt,
+                       b.tiles_c);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -240,7 +240,7 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
     // songs).
     const bool beat_late = c->tail_mode == 1 || (c->tail_mode < 0 && only_chunk);
     if (!beat_late) { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
-    { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st); }
+    { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st, c->stft_shape); }
     if (multi) {
         HIP_TRY(hipEventRecord(slot.ev_stft, st));
         HIP_TRY(hipStreamWaitEvent(sc, slot.ev_stft, 0));

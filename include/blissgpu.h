@@ -97,6 +97,9 @@ int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
 #define BLISSGPU_OPT_TAIL_SPLIT 6       /* one-chunk batches: P >= 2 = the tuning estimate and the contraction run in P pieces of the
                                            songs (at most 8), the contraction of piece k beside the tuning estimate of piece
                                            k + 1; 0 / 1 = unsplit (default: see DESIGN.md section 3b) */
+#define BLISSGPU_OPT_STFT_SHAPE 7       /* FFT-8192 kernel: 0 = four workgroups per CU, window in registers (default); 1 = the narrow
+                                           form (five per CU: window loaded per frame, transposes in two halves); 2 / 3 = one of
+                                           the two changes alone.  Same rows bit for bit; 1 is 8 % slower */
 #define BLISSGPU_OPT_DEBUG_CHROMA 5     /* 1: the contraction also keeps chroma_stft's matrix and the assembly the interval
                                            means of the chunk for the CHROMA / INTERVAL taps below (96 B per frame); such a
                                            batch must fit ONE chunk (BLISSGPU_ERR_INVALID otherwise) */

@@ -1,0 +1,91 @@
+"""GPU tests added in round 5 (-m gpu) beside tests/test_gpu_resample.py:
+
+  * the two shapes of the FFT-8192 kernel (BLISSGPU_OPT_STFT_SHAPE: 4 workgroups per CU with the window in registers -- production --
+    against the narrow form, 5 per CU, window loaded per frame and the transposes in two halves; plus the two measurement forms that
+    carry one change each) give the same spectrogram and the same rows, bit for bit, edge frames included
+  * a BLISSGPU_OPT_DEBUG_CHROMA batch that needs more than one chunk is refused (the taps are one buffer per context)
+  * blissgpu_default_reset / the ten-year clamp of the single-song deadline are callable and harmless
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bliss():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import bliss_rs_amd
+
+    return bliss_rs_amd
+
+
+def _pack(songs):
+    lens = [len(s) for s in songs]
+    offs = np.concatenate([[0], np.cumsum([(l + 63) // 64 * 64 for l in lens])[:-1]]).astype(np.uint64)
+    buf = np.zeros(int(offs[-1]) + lens[-1] + 64, np.float32)
+    for s, o in zip(songs, offs):
+        buf[int(o):int(o) + len(s)] = s
+    return buf, offs, lens
+
+
+def test_stft_shapes_give_identical_rows(bliss, oracle):
+    import torch
+
+    # lengths around the framing's edges: the minimum (every frame reflects at both ends), one frame more, a song whose
+    # last super-tile is ragged, three minutes, and 65 songs so that several workgroups of a super-tile are idle
+    lens = [8192, 8193, 10397, 12602, 70000, 141121, 22050 * 30 + 7, 3969000] + [22050 * 5 + 11 * i for i in range(60)]
+    songs = [oracle.white_noise(4000 + i, n) for i, n in enumerate(lens)]
+    buf, offs, ls = _pack(songs)
+    d_buf = torch.from_numpy(buf).cuda()
+    ctx = bliss.Context(0)
+    rows, specs = {}, {}
+    for shape in (0, 1, 2, 3):
+        ctx.set_option("stft_shape", shape)
+        out, status = ctx.analyze(d_buf, offs, ls, 2)
+        ctx.synchronize()
+        assert (status.cpu().numpy() == 0).all()
+        rows[shape] = out.cpu().numpy()
+        specs[shape] = [ctx.debug_fetch("spectrogram", i) for i in (0, 1, 2, 5, 7)]
+    ctx.set_option("stft_shape", 0)
+    for shape in (1, 2, 3):
+        assert np.array_equal(rows[shape].view(np.uint32), rows[0].view(np.uint32)), shape
+        for a, b in zip(specs[shape], specs[0]):
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), shape
+    ref = oracle.song_analyze(songs[4], 2)
+    assert np.abs(rows[1][4] - ref).max() < 1e-4  # (and the rows are the right ones: white noise, tempo floor 3e-5)
+    ctx.close()
+
+
+def test_debug_chroma_needs_one_chunk(bliss, oracle):
+    import torch
+
+    from bliss_rs_amd import _ffi
+
+    songs = [oracle.white_noise(4100 + i, 22050 * 20) for i in range(12)]
+    buf, offs, ls = _pack(songs)
+    ctx = bliss.Context(0)
+    ctx.set_option("debug_chroma", 1)
+    ctx.set_workspace_limit(32 << 20)  # a 20-second song needs ~4 MB: a dozen of them do not fit 32 MB -> several chunks
+    with pytest.raises(bliss.BlissGpuError) as e:
+        ctx.analyze(torch.from_numpy(buf).cuda(), offs, ls, 2)
+    assert e.value.code == _ffi.ERR_INVALID and "one chunk" in str(e.value)
+    ctx.set_option("debug_chroma", 0)
+    out, status = ctx.analyze(torch.from_numpy(buf).cuda(), offs, ls, 2)  # the same batch without the taps: several chunks, fine
+    ctx.synchronize()
+    assert ctx.last_chunks() > 1 and (status.cpu().numpy() == 0).all()
+    ctx.close()
+
+
+def test_default_reset_and_deadline_clamp(bliss, oracle):
+    from bliss_rs_amd import _ffi
+
+    L = _ffi.lib()
+    assert L.blissgpu_set_single_song_timeout_ms(2**63 - 1) == 0  # "never": clamped, must not overflow the deadline clock
+    a = bliss.Song.analyze(oracle.white_noise(5, 22050 * 4)).as_arr1()
+    assert L.blissgpu_default_reset() == 0
+    b = bliss.Song.analyze(oracle.white_noise(5, 22050 * 4)).as_arr1()
+    assert np.array_equal(a, b)
+    assert L.blissgpu_set_single_song_timeout_ms(0) == 0  # back to the default
