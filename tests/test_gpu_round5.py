@@ -89,3 +89,22 @@ def test_default_reset_and_deadline_clamp(bliss, oracle):
     b = bliss.Song.analyze(oracle.white_noise(5, 22050 * 4)).as_arr1()
     assert np.array_equal(a, b)
     assert L.blissgpu_set_single_song_timeout_ms(0) == 0  # back to the default
+
+
+def test_decoded_feed_across_staging_groups(bliss, oracle):
+    """24 three-minute songs as three decoders would deliver them -- 44.1 kHz stereo s16, 22 050 Hz mono f32 (copied verbatim), 48 kHz
+    mono s16 -- in one blissgpu_analyze_batch_decoded call: 0.8 GB of raw samples, i.e. several 512 MiB staging groups with different
+    raw / PCM layouts alternating between the two buffers.  Every row must equal the same song analysed alone, bit for bit."""
+    rng = np.random.default_rng(12)
+    songs, rates = [], []
+    for i in range(8):
+        songs.append(rng.integers(-12000, 12000, (44100 * 180, 2)).astype(np.int16)); rates.append(44100)
+        songs.append(oracle.white_noise(4200 + i, 22050 * 180)); rates.append(22050)
+        songs.append(rng.integers(-12000, 12000, 48000 * 180 + 17 * i).astype(np.int16)); rates.append(48000)
+    res = bliss.analyze_decoded_batch(songs, rates)
+    assert all(not isinstance(r, bliss.BlissError) for r in res)
+    for k in (0, 1, 2, 9, 10, 11, 21, 22, 23):
+        alone = bliss.Song.analyze_decoded(songs[k], rates[k]).as_arr1()
+        assert np.array_equal(alone.view(np.uint32), res[k].as_arr1().view(np.uint32)), k
+    ref = oracle.song_analyze(oracle.decode_to_mono(songs[2], 48000), 2)
+    assert np.abs(res[2].as_arr1() - ref).max() < 1e-4
