@@ -108,3 +108,42 @@ def test_decoded_feed_across_staging_groups(bliss, oracle):
         assert np.array_equal(alone.view(np.uint32), res[k].as_arr1().view(np.uint32)), k
     ref = oracle.song_analyze(oracle.decode_to_mono(songs[2], 48000), 2)
     assert np.abs(res[2].as_arr1() - ref).max() < 1e-4
+
+
+def test_threads_calling_analyze_decoded_are_coalesced(bliss, oracle):
+    """The reference's worker pool, one thread per file (src/song/decoder.rs:299-329), with decoders that deliver their own rates:
+    16 threads x 6 calls of Song.analyze_decoded on 44.1 / 48 / 22.05 / 96 kHz songs.  Concurrent calls are coalesced into device
+    batches of MIXED formats; every row must equal the same call made alone."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    rng = np.random.default_rng(3)
+    cases = [
+        (rng.integers(-9000, 9000, (44100 * 12, 2)).astype(np.int16), 44100),
+        (rng.integers(-9000, 9000, 48000 * 9).astype(np.int16), 48000),
+        (oracle.white_noise(4300, 22050 * 10), 22050),
+        ((rng.random((96000 * 7, 2), np.float32) - 0.5).astype(np.float32), 96000),
+        (rng.integers(-2**30, 2**30, 44100 * 8).astype(np.int32), 44100),
+        (rng.integers(-9000, 9000, 15000).astype(np.int16), 44100),  # too short once converted
+    ]
+    serial = []
+    for x, r in cases:
+        try:
+            serial.append(bliss.Song.analyze_decoded(x, r).as_arr1())
+        except bliss.AnalysisError as e:
+            serial.append(str(e))
+
+    def work(i):
+        x, r = cases[i % len(cases)]
+        try:
+            return i % len(cases), bliss.Song.analyze_decoded(x, r).as_arr1()
+        except bliss.AnalysisError as e:
+            return i % len(cases), str(e)
+
+    with ThreadPoolExecutor(16) as ex:
+        got = list(ex.map(work, range(96)))
+    for k, row in got:
+        if isinstance(serial[k], str):
+            assert row == serial[k]
+        else:
+            assert np.array_equal(row.view(np.uint32), serial[k].view(np.uint32)), k
+    assert isinstance(serial[5], str) and "too short" in serial[5]
