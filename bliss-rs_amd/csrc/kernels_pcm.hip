@@ -83,7 +83,7 @@ void launch_pcm_convert(const void* in, int sample_format, uint32_t channels, fl
 // A workgroup produces a tile of consecutive outputs: the input span the tile needs is staged in LDS once (coalesced
 // loads, converted to f32, the mirrors resolved there), the filter bank too when it fits (44.1 kHz: 66 floats; 48 kHz:
 // 147 phases x 72 taps = 42 KB); a thread computes four outputs.  The feed is PCIe-bound: a 3-minute 44.1 kHz stereo s16
-// song is 32 MB on the link (0.6 ms) and 0.1 ms of this kernel.
+// song is 32 MB on the link (0.6 ms) and 0.06 ms of resample2_kernel below (0.12 ms of this general kernel).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int RS_THREADS = 256, RS_PER_THREAD = 4, RS_TILE = RS_THREADS * RS_PER_THREAD;
 constexpr int RS_SPAN_CAP = 10240;  // floats of input span per tile at most (the host sizes the tile to fit)
@@ -185,9 +185,98 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(ResampleArgs a) {
     }
 }
 
+// ---- the 2 : 1 case (44 100 -> 22 050 Hz: one phase, 66 taps) -- what almost every file needs -- with its own kernel: the 66
+// coefficients are wave-uniform (scalar loads), a thread computes FOUR CONSECUTIVE outputs from 72 samples it reads once
+// (18 x 16 bytes from LDS instead of 4 x 66 words: the windows of neighbouring outputs overlap in all but two samples), and a
+// stereo file is read once for both channels.  Same operands, same order of the same fused multiply-adds per output.
+constexpr int R2_TAPS = 66, R2_CENTER = 32, R2_SPAN = 2 * RS_TILE + 128;  // floats per channel: 2 (tile - 1) + taps, padded
+
+template <typename SampleT, int CH>  // CH = 1 or 2
+__global__ __launch_bounds__(RS_THREADS) void resample2_kernel(ResampleArgs a) {
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) float span[CH][R2_SPAN];
+    const SampleT* __restrict__ in = reinterpret_cast<const SampleT*>(a.in);
+    const int t = threadIdx.x;
+    const uint64_t k0 = (uint64_t)blockIdx.x * RS_TILE;
+    if (k0 >= a.n_out) return;
+    const uint64_t k1 = k0 + RS_TILE < a.n_out ? k0 + RS_TILE : a.n_out;  // exclusive
+    const int64_t lo = 2 * (int64_t)k0 - R2_CENTER;                       // first tap of output k0
+    const int span_len = 2 * (int)(k1 - 1 - k0) + R2_TAPS;
+    for (int i = t; i < span_len; i += RS_THREADS) {
+        int64_t s = lo + i;
+        if (s < 0) s = -s;                                                     // x[-j] = x[j]
+        else if ((uint64_t)s >= a.frames) s = 2 * (int64_t)a.frames - 1 - s;   // x[n + j] = x[n - 1 - j]
+#pragma unroll
+        for (int c = 0; c < CH; c++) span[c][i] = pcm_sample(in, (uint64_t)CH * (uint64_t)s + (uint64_t)c);
+    }
+    __syncthreads();
+    float res[CH][4];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        float x[72];  // samples first(k0 + 4 t) .. + 71: output j of this thread uses x[2 j .. 2 j + 65]
+        const float4* src = reinterpret_cast<const float4*>(&span[c][8 * t]);
+#pragma unroll
+        for (int q = 0; q < 18; q++) {
+            const float4 v = src[q];
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+        float acc[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc[j][u] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < R2_TAPS; i++) {
+            const float f = a.bank[i];  // wave-uniform: a scalar load
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j][i & 7] = __builtin_fmaf(x[2 * j + i], f, acc[j][i & 7]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float b0 = acc[j][0] + acc[j][4], b1 = acc[j][1] + acc[j][5], b2 = acc[j][2] + acc[j][6], b3 = acc[j][3] + acc[j][7];
+            const float c0 = b0 + b2, c1 = b1 + b3;
+            res[c][j] = c0 + c1;
+        }
+    }
+    float y[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        y[j] = res[0][j];
+        if (CH == 2) {
+            const float m = 0.70710678118654752440f;  // (float)M_SQRT1_2, both matrix coefficients
+            const float l = res[0][j] * m, r = res[CH - 1][j] * m;
+            y[j] = l + r;
+        }
+    }
+    const uint64_t k = k0 + 4 * (uint64_t)t;
+    if (k + 3 < k1 && ((reinterpret_cast<uintptr_t>(a.out + k) & 15) == 0)) {
+        *reinterpret_cast<float4*>(a.out + k) = make_float4(y[0], y[1], y[2], y[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (k + j < k1) a.out[k + j] = y[j];
+    }
+}
+
+template <typename SampleT>
+static void launch_resample2(const ResampleArgs& a, uint32_t grid, hipStream_t st) {
+    if (a.channels == 1) hipLaunchKernelGGL((resample2_kernel<SampleT, 1>), dim3(grid), dim3(RS_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((resample2_kernel<SampleT, 2>), dim3(grid), dim3(RS_THREADS), 0, st, a);
+}
+
 hipError_t launch_resample(const void* in, int sample_format, uint32_t channels, uint64_t frames, const SwrPlan& p,
                            const float* d_bank, float* out, uint64_t n_out, hipStream_t st) {
     if (n_out == 0) return hipSuccess;
+    if (p.phase_count == 1 && p.src_incr == 1 && p.dst_incr == 2 && p.taps == R2_TAPS && p.center == R2_CENTER && channels <= 2) {
+        const uint64_t grid2 = (n_out + RS_TILE - 1) / RS_TILE;
+        if (grid2 > 0x7fffffffull) return hipErrorInvalidValue;
+        ResampleArgs a{in, out, d_bank, frames, n_out, p.dst_incr, p.src_incr, channels, (uint32_t)RS_TILE, p.taps, p.phase_count,
+                       p.center, 0, 0};
+        if (sample_format == BLISSGPU_SAMPLE_S16) launch_resample2<int16_t>(a, (uint32_t)grid2, st);
+        else if (sample_format == BLISSGPU_SAMPLE_S32) launch_resample2<int32_t>(a, (uint32_t)grid2, st);
+        else launch_resample2<float>(a, (uint32_t)grid2, st);
+        return hipGetLastError();
+    }
     // the tile's input span: (tile - 1) outputs further down the stream + one window, rounded up
     const uint64_t room = (uint64_t)(RS_SPAN_CAP - p.taps - 2);
     uint64_t tile = room * SWR_OUT_RATE / p.in_rate;
