@@ -57,7 +57,8 @@ def test_device_resampler_hits_the_reference_adler32(ctx, oracle, literals, name
     assert np.array_equal(got.view(np.uint32), oracle.decode_to_mono(samples, rate).view(np.uint32))
 
 
-@pytest.mark.parametrize("rate", [8000, 11025, 16000, 24000, 32000, 33075, 44056, 44100, 48000, 88200, 96000, 192000, 768000])
+@pytest.mark.parametrize("rate", [1000, 8000, 11025, 16000, 24000, 32000, 33075, 37800, 44056, 44100, 48000, 64000, 88200, 96000,
+                                  192000, 352800, 768000])
 def test_device_resampler_equals_oracle_bitwise(ctx, oracle, rate):
     rng = np.random.default_rng(rate)
     taps = oracle.swr_filter(rate)[1].taps
