@@ -444,3 +444,26 @@ def test_rust_binding_declarations_match_the_header():
         assert ret == rust_of(cret), (name, ret, cret)
         n += 1
     assert n >= 30, n
+
+
+def test_decoded_song_struct_is_the_same_in_c_rust_and_ctypes():
+    """blissgpu_decoded_song crosses the ABI by pointer: its fields, their order and their widths must agree between
+    include/blissgpu.h, bindings/rust/gpu.rs (#[repr(C)]) and bliss_rs_amd._ffi.DecodedSong."""
+    import ctypes as C
+    import re
+
+    header = open(os.path.join(ROOT, "include", "blissgpu.h")).read()
+    body = re.search(r"typedef struct blissgpu_decoded_song \{(.*?)\} blissgpu_decoded_song;", header, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", " ", body, flags=re.S)
+    c_fields = [(m.group(2), " ".join(m.group(1).split())) for m in re.finditer(r"([a-z_0-9 ]+?\**)\s*\b([a-z_]+);", body)]
+    assert c_fields == [("pcm", "const void *"), ("frames", "uint64_t"), ("sample_rate", "uint32_t"), ("channels", "uint16_t"),
+                        ("sample_format", "uint16_t")], c_fields
+    rs = open(os.path.join(ROOT, "bindings", "rust", "gpu.rs")).read()
+    rbody = re.search(r"#\[repr\(C\)\]\s*#\[derive\(Clone, Copy\)\]\s*pub struct blissgpu_decoded_song \{(.*?)\}", rs, flags=re.S).group(1)
+    r_fields = [(m.group(1), m.group(2).strip()) for m in re.finditer(r"pub ([a-z_]+): ([^,]+),", rbody)]
+    assert r_fields == [("pcm", "*const c_void"), ("frames", "u64"), ("sample_rate", "u32"), ("channels", "u16"), ("sample_format", "u16")]
+    from bliss_rs_amd import _ffi
+
+    assert [(n, t) for n, t in _ffi.DecodedSong._fields_] == [("pcm", C.c_void_p), ("frames", C.c_uint64), ("sample_rate", C.c_uint32),
+                                                             ("channels", C.c_uint16), ("sample_format", C.c_uint16)]
+    assert C.sizeof(_ffi.DecodedSong) == 24
