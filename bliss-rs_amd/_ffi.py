@@ -18,6 +18,7 @@ SONG_OK, SONG_TOO_SHORT = 0, 1
 METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_MAHALANOBIS = 0, 1, 2
 OPT_SERIAL, OPT_TAIL_MODE, OPT_PIPELINE_CHUNKS, OPT_CAND_BUDGET, OPT_ROLLOFF_EXACT_ALL, OPT_DEBUG_CHROMA, OPT_TAIL_SPLIT = 0, 1, 2, 3, 4, 5, 6
 OPT_STFT_SHAPE = 7
+OPT_FLUX_ORDER = 8
 
 _f32p = C.POINTER(C.c_float)
 _f64p = C.POINTER(C.c_double)

@@ -369,6 +369,7 @@ int blissgpu_ctx_set_option(blissgpu_ctx* c, int option, int64_t value) {
         case BLISSGPU_OPT_ROLLOFF_EXACT_ALL: c->rolloff_exact_all = value != 0; break;
         case BLISSGPU_OPT_DEBUG_CHROMA: c->debug_chroma = value != 0; break;
         case BLISSGPU_OPT_TAIL_SPLIT: c->tail_split = (int)value; break;
+        case BLISSGPU_OPT_FLUX_ORDER: c->flux_order = value != 0; break;
         case BLISSGPU_OPT_STFT_SHAPE: c->stft_shape = (value >= 0 && value <= 3) ? (int)value : 0; break;
         case BLISSGPU_OPT_CAND_BUDGET: c->cand_budget = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 714)); break;
         default: return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_set_option", "unknown option");

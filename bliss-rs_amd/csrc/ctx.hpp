@@ -142,6 +142,7 @@ struct blissgpu_ctx {
                                        // per-song tails have a fixed latency per launch, so more chunks than memory needs lose)
     hipEvent_t ev_interop = nullptr;
     bool rolloff_exact_all = false;    // BLISSGPU_OPT_ROLLOFF_EXACT_ALL (tests)
+    bool flux_order = false;           // BLISSGPU_OPT_FLUX_ORDER: SpecFlux summed in the reference's bin order (strict; +19 % on the FFT-512 kernel)
     int stft_shape = 0;                // BLISSGPU_OPT_STFT_SHAPE: 0 = four workgroups / CU, window in registers (production); 1 = the narrow form
     int tail_split = 0;                // BLISSGPU_OPT_TAIL_SPLIT: one-chunk batches run the tuning estimate + contraction in two halves
     bool debug_chroma = false;         // BLISSGPU_OPT_DEBUG_CHROMA (tests): keep the chroma matrix / interval means of the last chunk

@@ -176,7 +176,7 @@ struct Batch {
     uint32_t max_nt;          // longest song's timbral-frame count
 };
 
-void launch_fft512(const Batch&, const Workspace&, const DeviceTables&, hipStream_t, bool rolloff_exact_all = false);
+void launch_fft512(const Batch&, const Workspace&, const DeviceTables&, hipStream_t, bool rolloff_exact_all = false, bool seq_flux = false);
 void launch_rolloff_fix(const Batch&, const Workspace&, uint64_t total_t, hipStream_t);
 void launch_onset(const Batch&, const Workspace&, hipStream_t);
 void launch_beat(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);

@@ -229,7 +229,8 @@ __device__ __forceinline__ void stats128(const f2 r0, const f2 r1, const f2 r2, 
     add_lane_bit(zc, x3 ^ shifted(y3, (y2 >> 15) & LOW));
 }
 
-template <bool ROLLOFF_EXACT_ALL>  // true: tests only -- every frame takes the reference-order pass
+// ROLLOFF_EXACT_ALL: tests only -- every frame takes the reference-order pass.  SEQ_FLUX: BLISSGPU_OPT_FLUX_ORDER.
+template <bool ROLLOFF_EXACT_ALL, bool SEQ_FLUX>
 __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict__ pcm,
                                                         const SongDesc* __restrict__ songs, uint32_t n_songs,
                                                         const uint32_t* __restrict__ pfx_f,
@@ -329,10 +330,27 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
             // of two floats is never rounded to zero, adding +0 to a non-negative f changes nothing, and max drops a NaN
             // difference exactly as the comparison does) in three instructions per bin instead of four
             float f = 0.0f;
+            if constexpr (SEQ_FLUX) {
+            // BLISSGPU_OPT_FLUX_ORDER = 1: the 257 terms added one by one in bin order, as src/aubio.rs:455-467 does -- lane l
+            // continues lane l - 1's running sum (16 rounds of 16 dependent adds).  The 16-per-lane + tree order of the default
+            // deviates from that by 1.7e-7 rms even on exact magnitudes, which is what put the device's tempo on the noisier
+            // side of the f32 floor (profiles/r05_flux_order_ab6.txt); this form costs the kernel 19 %
+#pragma unroll 1
+            for (int step = 0; step < 16; step++) {
+                const float carry = dpp_mov<0x111>(f);  // row_shr:1 -- lane l receives lane l - 1's running sum (lane 0: 0)
+                if (l == step) {
+                    f = carry;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) f += fmaxf(cur.m[e] - prev.m[e], 0.0f);
+                }
+            }
+            f = __shfl(f, (threadIdx.x & 48) + 15, 64) + fmaxf(cur.nyq - prev.nyq, 0.0f);  // lane 15's total, then bin 256
+            } else {
 #pragma unroll
             for (int e = 0; e < 16; e++) f += fmaxf(cur.m[e] - prev.m[e], 0.0f);
             if (l == 0) f += fmaxf(cur.nyq - prev.nyq, 0.0f);
             f = row16_sum(f);
+            }
             if (J == 1 && share && k == k_begin + 1) {
                 // no previous tempo frame here: hand this frame's magnitudes to the group before
 #pragma unroll
@@ -477,14 +495,30 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
     if (grp + 1 < GROUPS_PER_WG && k_begin + FRAMES_PER_GROUP + 1 < (long)sd.n_f) {
         const long q = (k_begin + FRAMES_PER_GROUP) >> 1;
         float f = 0.0f;
+        const float cn = halo[grp + 1][256];
+        if constexpr (SEQ_FLUX) {
+        float hc[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) hc[e] = halo[grp + 1][16 * e + l];
+#pragma unroll 1
+        for (int step = 0; step < 16; step++) {
+            const float carry = dpp_mov<0x111>(f);
+            if (l == step) {
+                f = carry;
+#pragma unroll
+                for (int e = 0; e < 16; e++) f += fmaxf(hc[e] - A.m[e], 0.0f);
+            }
+        }
+        f = __shfl(f, (threadIdx.x & 48) + 15, 64) + fmaxf(cn - A.nyq, 0.0f);
+        } else {
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const float c = halo[grp + 1][16 * e + l];
             f += fmaxf(c - A.m[e], 0.0f);
         }
-        const float cn = halo[grp + 1][256];
         if (l == 0) f += fmaxf(cn - A.nyq, 0.0f);
         f = row16_sum(f);
+        }
         if (l == 0 && q < (long)sd.n_b) flux[sd.b_off + q] = f;
     }
 
@@ -510,9 +544,13 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
     }
 }
 
-void launch_fft512(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st, bool rolloff_exact_all) {
+void launch_fft512(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st, bool rolloff_exact_all, bool seq_flux) {
     if (b.tiles_f == 0) return;
-    hipLaunchKernelGGL(rolloff_exact_all ? fft512_kernel<true> : fft512_kernel<false>, dim3(b.tiles_f), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_f, t.hannz512,
+    auto k = fft512_kernel<false, false>;
+    if (rolloff_exact_all && seq_flux) k = fft512_kernel<true, true>;
+    else if (rolloff_exact_all) k = fft512_kernel<true, false>;
+    else if (seq_flux) k = fft512_kernel<false, true>;
+    hipLaunchKernelGGL(k, dim3(b.tiles_f), dim3(256), 0, st, b.pcm, b.songs, b.n_songs, b.pfx_f, t.hannz512,
                        t.tw512, w.centroid, w.rolloff, w.flatness, w.flux, w.e256, w.zc256, w.roll_fix);
 }
 

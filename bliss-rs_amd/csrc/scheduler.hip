@@ -223,7 +223,7 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
     HIP_TRY(hipMemsetAsync(w.h1, 0, (size_t)ns * H1_BINS * 4, st));
     HIP_TRY(hipMemsetAsync(w.hist100, 0, (size_t)ns * N_TUNING * 4, st));
     HIP_TRY(hipMemsetAsync(w.cand_cursor, 0, 16, st));
-    { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st, c->rolloff_exact_all); }
+    { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st, c->rolloff_exact_all, c->flux_order); }
     { Prof p(c, K_ROLLFIX); launch_rolloff_fix(b, w, t.tot_t, st); }
     { Prof p(c, K_ONSET); launch_onset(b, w, st); }
     // tails: the reference runs them as the tempo / timbral / loudness threads of src/song/mod.rs:432-491

@@ -61,7 +61,7 @@ class Context:
     OPTIONS = {"serial": _ffi.OPT_SERIAL, "tail_mode": _ffi.OPT_TAIL_MODE, "pipeline_chunks": _ffi.OPT_PIPELINE_CHUNKS,
                "cand_budget": _ffi.OPT_CAND_BUDGET, "rolloff_exact_all": _ffi.OPT_ROLLOFF_EXACT_ALL,
                "debug_chroma": _ffi.OPT_DEBUG_CHROMA, "tail_split": _ffi.OPT_TAIL_SPLIT,
-               "stft_shape": _ffi.OPT_STFT_SHAPE}
+               "stft_shape": _ffi.OPT_STFT_SHAPE, "flux_order": _ffi.OPT_FLUX_ORDER}
 
     def set_option(self, name: str, value: int):
         """Scheduling knobs for the measurement tools and the tests (blissgpu_ctx_set_option)."""

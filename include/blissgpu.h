@@ -97,6 +97,12 @@ int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
 #define BLISSGPU_OPT_TAIL_SPLIT 6       /* one-chunk batches: P >= 2 = the tuning estimate and the contraction run in P pieces of the
                                            songs (at most 8), the contraction of piece k beside the tuning estimate of piece
                                            k + 1; 0 / 1 = unsplit (default: see DESIGN.md section 3b) */
+#define BLISSGPU_OPT_FLUX_ORDER 8       /* 1: SpecFlux (src/aubio.rs:455-467) adds its 257 terms one by one in bin order, as the
+                                           reference does, instead of 16 per lane + a tree.  The default order deviates from the
+                                           reference's by 1.7e-7 rms per value -- inside every tolerance, and the reason the tempo of
+                                           white noise sits on the noisier side of the f32-FFT floor; with this option the device's
+                                           tempo is as close to the f64-FFT oracle as a plain f32 FFT's.
+                                           FFT-512 kernel +19 %, step +6 %.  Default 0 */
 #define BLISSGPU_OPT_STFT_SHAPE 7       /* FFT-8192 kernel: 0 = four workgroups per CU, window in registers (default); 1 = the narrow
                                            form (five per CU: window loaded per frame, transposes in two halves); 2 / 3 = one of
                                            the two changes alone.  Same rows bit for bit; 1 is 8 % slower */

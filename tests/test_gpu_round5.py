@@ -147,3 +147,34 @@ def test_threads_calling_analyze_decoded_are_coalesced(bliss, oracle):
         else:
             assert np.array_equal(row.view(np.uint32), serial[k].view(np.uint32)), k
     assert isinstance(serial[5], str) and "too short" in serial[5]
+
+
+def test_flux_order_option_follows_the_reference_sum(bliss, oracle):
+    """BLISSGPU_OPT_FLUX_ORDER = 1 adds SpecFlux's 257 terms in the reference's bin order (src/aubio.rs:455-467).  Only the
+    tempo chain may change (every other feature bit-identical), and the onset series must move TOWARDS the oracle's: the default
+    order (16 per lane + a tree) deviates from the sequential sum by 1.7e-7 rms on its own (tests/tools/fft_error_model_order.py)."""
+    import torch
+
+    songs = [oracle.white_noise(4400 + i, 22050 * 40) for i in range(6)]
+    buf, offs, ls = _pack(songs)
+    d_buf = torch.from_numpy(buf).cuda()
+    ctx = bliss.Context(0)
+    rows, flux = {}, {}
+    for opt in (0, 1):
+        ctx.set_option("flux_order", opt)
+        out, status = ctx.analyze(d_buf, offs, ls, 2)
+        ctx.synchronize()
+        rows[opt] = out.cpu().numpy()
+        flux[opt] = [ctx.debug_fetch("flux", i) for i in range(len(songs))]
+    ctx.set_option("flux_order", 0)
+    assert np.array_equal(rows[0][:, 1:].view(np.uint32), rows[1][:, 1:].view(np.uint32))  # tempo is feature 0
+    dev = {0: [], 1: []}
+    for i, x in enumerate(songs):
+        ref = oracle.BPMDesc().run(x).series()[0].astype(np.float64)
+        for opt in (0, 1):
+            f = flux[opt][i][: len(ref)].astype(np.float64)
+            dev[opt].append(np.sqrt(((f - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()))
+        assert abs(rows[1][i, 0] - oracle.song_analyze(x, 2)[0]) < 1e-4
+    print("rms relative deviation of the onset series from the oracle's: default order", np.mean(dev[0]), " reference order", np.mean(dev[1]))
+    assert np.mean(dev[1]) < 0.8 * np.mean(dev[0]), (dev[0], dev[1])
+    ctx.close()

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--samples", type=int, default=3969000)
     ap.add_argument("--threads", type=int, default=64)
     ap.add_argument("--noise-floor", action="store_true")
+    ap.add_argument("--flux-order", type=int, default=0, help="BLISSGPU_OPT_FLUX_ORDER: 1 = SpecFlux summed in the reference's bin order")
     args = ap.parse_args()
     import torch
 
@@ -35,6 +36,7 @@ def main():
 
     n, N = args.songs, args.samples
     ctx = bliss.Context(0)
+    ctx.set_option("flux_order", args.flux_order)
     offs = np.arange(n, dtype=np.uint64) * np.uint64(N)
     lens = np.full(n, N, np.uint64)
     pcm = torch.empty(n * N, dtype=torch.float32, device="cuda")

@@ -77,6 +77,7 @@ int main(int argc, char** argv) {
     if (const char* e = std::getenv("KBENCH_WS_LIMIT_MB")) OK(p_blissgpu_ctx_set_workspace_limit(c, (uint64_t)std::atoll(e) << 20));
     if (const char* e = std::getenv("KBENCH_SERIAL")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_SERIAL, std::atoi(e)));
     if (const char* e = std::getenv("KBENCH_TAIL_MODE")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_TAIL_MODE, std::atoi(e)));
+    if (const char* e = std::getenv("KBENCH_FLUX_ORDER")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_FLUX_ORDER, std::atoi(e)));
     if (const char* e = std::getenv("KBENCH_STFT_SHAPE")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_STFT_SHAPE, std::atoi(e)));
     if (const char* e = std::getenv("KBENCH_TAIL_SPLIT")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_TAIL_SPLIT, std::atoi(e)));
     if (const char* e = std::getenv("KBENCH_PIPELINE_CHUNKS")) OK(p_blissgpu_ctx_set_option(c, BLISSGPU_OPT_PIPELINE_CHUNKS, std::atoi(e)));
