@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--songs", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--threads", type=int, default=64)
+    ap.add_argument("--flux-order", type=int, default=0, help="BLISSGPU_OPT_FLUX_ORDER")
     ap.add_argument("--mods", action="store_true", help="silent gaps, DC offsets, fades, barely-long-enough songs on top")
     args = ap.parse_args()
     import torch
@@ -109,6 +110,7 @@ def main():
     for s, o in zip(songs, offs):
         buf[int(o):int(o) + len(s)] = s
     ctx = bliss.Context(0)
+    ctx.set_option("flux_order", args.flux_order)
     out, status = ctx.analyze(torch.from_numpy(buf).cuda(), offs, lens, 2)
     ctx.synchronize()
     got = out.cpu().numpy()

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--songs", type=int, default=768)
     ap.add_argument("--seeds", type=int, nargs="+", default=[1, 2, 3])
     ap.add_argument("--threads", type=int, default=64)
+    ap.add_argument("--flux-order", type=int, default=0, help="BLISSGPU_OPT_FLUX_ORDER")
     ap.add_argument("--ws-limit-gb", type=float, default=4.0, help="small slots force a multi-chunk pipeline")
     args = ap.parse_args()
     import torch
@@ -30,6 +31,7 @@ def main():
     import oracle as O
 
     ctx = bliss.Context(0)
+    ctx.set_option("flux_order", args.flux_order)
     ctx.set_workspace_limit(int(args.ws_limit_gb * (1 << 30)))
     for seed in args.seeds:
         rng = np.random.default_rng(seed)
