@@ -146,6 +146,23 @@ def test_cue_tracks_through_the_device(bliss, ctx, oracle, literals):
     assert np.array_equal(rows1[:, :10], rows[:, :10])
 
 
+def test_cue_helper_equals_the_hand_built_slices(bliss, ctx, literals):
+    # bliss_rs_amd.cue.analyze_cue_tracks = the steps of the test above behind the interface a host would call
+    cue = literals["resample"]["cue"]
+    samples, rate = decoded_audio(cue["file"])
+    secs = [m * 60 + s + f / 75.0 for m, s, f in cue["index_mm_ss_ff"]]
+    res = bliss.cue.analyze_cue_tracks(ctx, samples, rate, secs)
+    assert bliss.cue.cue_track_bounds(secs, 496272) == cue_bounds(cue["index_mm_ss_ff"], 496272)
+    for r, exp in zip(res, cue["tracks"]):
+        assert np.abs(r.as_arr1() - np.array(exp, np.float32)).max() < FEATURE_TOL
+    v1 = bliss.cue.analyze_cue_tracks(ctx, samples, rate, secs, bliss.AnalysisOptions(features_version=1))
+    for r, exp in zip(v1, literals["resample"]["cue_v1"]["tracks"]):
+        assert len(r.as_arr1()) == 20 and np.abs(r.as_arr1() - np.array(exp, np.float32))[10:].max() < FEATURE_TOL
+    # a track shorter than the largest window is the reference's AnalysisError in that slot, not a failed call
+    short = bliss.cue.analyze_cue_tracks(ctx, samples, rate, [0.0, 22.4])
+    assert isinstance(short[1], bliss.AnalysisError) and not isinstance(short[0], bliss.BlissError)
+
+
 def test_analyze_decoded_single_song(bliss, oracle, literals):
     # Song::analyze on FFmpegDecoder's output for the 44.1 kHz stereo twin of the golden song, through the single-song front
     samples, rate = decoded_audio("s32_stereo_44_1_kHz.flac")
