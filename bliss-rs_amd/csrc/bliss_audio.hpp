@@ -251,6 +251,65 @@ inline std::vector<BlissResult<Analysis>> analyze_decoded_batch(const std::vecto
     return res;
 }
 
+// ---- CUE tracks as slices of one decoded buffer: BlissCueFile::get_songs (src/cue.rs:205-246) ----
+// (start, end) sample ranges of the tracks of one FILE entry: `(index.as_secs_f32() * SAMPLE_RATE as f32) as usize` for each
+// track's first INDEX; the last track runs to the end of the decoded file
+inline std::vector<std::pair<uint64_t, uint64_t>> cue_track_bounds(const std::vector<float>& index_seconds, uint64_t n_samples) {
+    std::vector<std::pair<uint64_t, uint64_t>> b;
+    for (size_t i = 0; i < index_seconds.size(); i++) {
+        const uint64_t s = (uint64_t)(index_seconds[i] * (float)BLISSGPU_SAMPLE_RATE);
+        const uint64_t e = i + 1 < index_seconds.size() ? (uint64_t)(index_seconds[i + 1] * (float)BLISSGPU_SAMPLE_RATE) : n_samples;
+        b.emplace_back(s, e);
+    }
+    return b;
+}
+// The audio file of a CUE sheet as the decoder delivered it (`frames` frames of `channels` interleaved samples at `sample_rate`) ->
+// one result per track: the file is converted ONCE to mono 22 050 Hz on the device (FFmpegDecoder's conversion), the tracks are
+// (offset, length) slices of that device buffer.  Sheet parsing (the reference uses the rcue crate) stays with the host.
+inline std::vector<BlissResult<Analysis>> analyze_cue_tracks(const void* pcm, int sample_format, uint32_t channels, uint64_t frames,
+                                                             uint32_t sample_rate, const std::vector<float>& index_seconds,
+                                                             const AnalysisOptions& opt = {}) {
+    struct Dev {  // device scratch of this call
+        blissgpu_ctx* ctx = nullptr;
+        void *raw = nullptr, *mono = nullptr, *rows = nullptr, *status = nullptr;
+        ~Dev() { blissgpu_free(raw); blissgpu_free(mono); blissgpu_free(rows); blissgpu_free(status); if (ctx) blissgpu_ctx_destroy(ctx); }
+    } d;
+    const size_t sample_bytes = sample_format == BLISSGPU_SAMPLE_S16 ? 2 : 4;
+    const uint64_t n_mono = blissgpu_resampled_len(frames, sample_rate);
+    const auto bounds = cue_track_bounds(index_seconds, n_mono);
+    const uint32_t n = static_cast<uint32_t>(bounds.size());
+    const size_t dft = feature_count(opt.features_version);
+    std::vector<uint64_t> off(n), len(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (bounds[i].first > bounds[i].second || bounds[i].second > n_mono) throw DecodingError("CUE index beyond the end of the audio file");
+        off[i] = bounds[i].first;
+        len[i] = bounds[i].second - bounds[i].first;
+    }
+    check(blissgpu_ctx_create(0, &d.ctx));
+    check(blissgpu_malloc(&d.raw, std::max<uint64_t>(1, frames * channels * sample_bytes)));
+    check(blissgpu_malloc(&d.mono, std::max<uint64_t>(1, n_mono) * 4 + 256));
+    check(blissgpu_malloc(&d.rows, std::max<size_t>(1, n * dft) * 4));
+    check(blissgpu_malloc(&d.status, std::max<uint32_t>(1, n) * 4));
+    if (frames) check(blissgpu_memcpy_h2d(d.ctx, d.raw, pcm, frames * channels * sample_bytes));
+    check(blissgpu_pcm_decode_device(d.ctx, d.raw, sample_format, channels, frames, sample_rate, static_cast<float*>(d.mono)));
+    std::vector<float> out(n * dft);
+    std::vector<int32_t> status(n);
+    if (n) {
+        check(blissgpu_analyze_batch_device(d.ctx, static_cast<const float*>(d.mono), off.data(), len.data(), n,
+                                            static_cast<uint32_t>(opt.features_version), static_cast<float*>(d.rows),
+                                            static_cast<int32_t*>(d.status)));
+        check(blissgpu_memcpy_d2h(d.ctx, out.data(), d.rows, out.size() * 4));
+        check(blissgpu_memcpy_d2h(d.ctx, status.data(), d.status, status.size() * 4));
+    }
+    std::vector<BlissResult<Analysis>> res;
+    res.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (status[i] == BLISSGPU_SONG_OK) res.emplace_back(Analysis(std::vector<float>(out.begin() + i * dft, out.begin() + (i + 1) * dft), opt.features_version));
+        else res.emplace_back(AnalysisError("empty or too short song."));
+    }
+    return res;
+}
+
 // ---- Decoder trait (src/song/decoder.rs:34-333) ----
 struct PreAnalyzedSong {
     std::string path;

@@ -29,7 +29,7 @@ struct RawS16Decoder : Decoder {  // ffmpeg's s16 -> flt conversion: sample / 32
 };
 
 int main(int argc, char** argv) {
-    CHECK(argc == 3 || argc == 4 || argc == 6);
+    CHECK(argc == 3 || argc == 4 || argc == 6 || argc == 8);
     // test_analysis_too_small (src/song/mod.rs:539-551)
     try { Song::analyze({0.0f}); CHECK(false); } catch (const BlissError& e) { CHECK(e == AnalysisError("empty or too short song.")); }
     try { Song::analyze({}); CHECK(false); } catch (const BlissError& e) { CHECK(e == AnalysisError("empty or too short song.")); }
@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
         CHECK(std::get<BlissError>(r[1]) == AnalysisError("empty or too short song."));
     }
     // stereo decoder output: the mono downmix runs on the device ((L + R) * SQRT_2 / 2, src/song/decoder/symphonia.rs:281-285)
-    if (argc == 4) {
+    if (argc >= 4) {
         std::ifstream f(argv[3], std::ios::binary);
         std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
         std::vector<int16_t> st(raw.size() / 2);
@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
     }
     // decoder output at another rate (44.1 kHz stereo, 24-bit samples in s32): FFmpegDecoder's conversion runs on the device
     // (src/song/decoder/ffmpeg.rs:36-109); argv[5] holds the row the Python mirror got from the same call
-    if (argc == 6) {
+    if (argc >= 6) {
         std::ifstream f(argv[4], std::ios::binary);
         std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
         std::vector<int32_t> st(raw.size() / 4);
@@ -85,6 +85,25 @@ int main(int argc, char** argv) {
         auto r = analyze_decoded_batch(lib);
         CHECK(std::get<Analysis>(r[0]) == got);
         CHECK(std::get<BlissError>(r[1]) == AnalysisError("empty or too short song."));
+    }
+    // BlissCue::songs_from_path on data/testcue.cue (src/cue.rs:270-415): argv[6] = the 44.1 kHz stereo s16 frames of testcue.flac,
+    // argv[7] = the 3 x 23 literals the reference asserts; the tracks are slices of ONE device-side conversion
+    if (argc == 8) {
+        std::ifstream f(argv[6], std::ios::binary);
+        std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        std::vector<int16_t> st(raw.size() / 2);
+        std::memcpy(st.data(), raw.data(), st.size() * 2);
+        std::vector<float> want(69);
+        { std::ifstream g(argv[7]); for (auto& v : want) g >> v; }
+        const std::vector<float> idx = {0.0f, 11.0f + 5.0f / 75.0f, 16.0f + 69.0f / 75.0f};  // INDEX 01 0:00:00, 0:11:05, 0:16:69
+        auto tracks = analyze_cue_tracks(st.data(), BLISSGPU_SAMPLE_S16, 2, st.size() / 2, 44100, idx);
+        CHECK(tracks.size() == 3);
+        for (size_t t = 0; t < 3; t++) {
+            const auto& a = std::get<Analysis>(tracks[t]).as_vec();
+            for (size_t i = 0; i < 23; i++) CHECK(std::fabs(a[i] - want[23 * t + i]) < 1e-5f);
+        }
+        const auto b = cue_track_bounds(idx, 496272);
+        CHECK(b[0].second == 244020 && b[1].first == 244020 && b[1].second == 373086 && b[2].second == 496272);
     }
     // bulk path: a missing file is reported, not fatal (src/song/decoder.rs:313-325)
     auto res = dec.analyze_paths({argv[1], "/nonexistent.raw"});

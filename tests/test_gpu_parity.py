@@ -632,7 +632,13 @@ def test_cpp_host_mirror(tmp_path, literals):
     s44.astype("<i4").tofile(raw44)
     exp44 = tmp_path / "expected44.txt"
     exp44.write_text(" ".join("%.9g" % v for v in bliss.Song.analyze_decoded(s44, rate).as_arr1()))
-    out = subprocess.run([str(exe), str(raw), str(exp), str(stereo), str(raw44), str(exp44)], capture_output=True, text=True,
-                         timeout=300)
+    cue, rate_cue = decoded_audio("testcue.flac")
+    assert rate_cue == 44100 and cue.dtype == np.int16 and cue.shape[1] == 2
+    rawcue = tmp_path / "testcue.s16"
+    cue.astype("<i2").tofile(rawcue)
+    expcue = tmp_path / "expected_cue.txt"
+    expcue.write_text(" ".join(repr(v) for t in literals["resample"]["cue"]["tracks"] for v in t))
+    out = subprocess.run([str(exe), str(raw), str(exp), str(stereo), str(raw44), str(exp44), str(rawcue), str(expcue)],
+                         capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout
