@@ -21,6 +21,7 @@ A "step" = one pass of Song::analyze over this GPU's batch (+ the RCCL all-gathe
 import argparse
 import json
 import os
+import statistics
 import subprocess
 import sys
 import time
@@ -595,35 +596,48 @@ def main():
                               res.ctypes.data, st.ctypes.data_as(C.POINTER(C.c_int32))))
                 return hf / (time.perf_counter() - t0)
 
-            run(L.blissgpu_analyze_batch, h_f32.data_ptr())       # warm-up: the context allocates its staging buffers
-            run(L.blissgpu_analyze_batch_s16, h_s16.data_ptr())   # ... and the raw-sample buffers of the s16 form
-            feed = {"songs": hf,
-                    "f32_pinned_songs_per_sec": round(run(L.blissgpu_analyze_batch, h_f32.data_ptr()), 1),
-                    "f32_pageable_songs_per_sec": round(run(L.blissgpu_analyze_batch, pageable.ctypes.data), 1),
-                    "s16_pinned_songs_per_sec": round(run(L.blissgpu_analyze_batch_s16, h_s16.data_ptr()), 1)}
+            def med3(f):   # every number of this section: one untimed call, then the median of three
+                f()
+                return round(statistics.median(f() for _ in range(3)), 1)
+
+            pageable_s16 = h_s16.numpy().copy()
+            feed = {"songs": hf, "each": "median of 3 calls after one untimed call",
+                    "f32_pinned_songs_per_sec": med3(lambda: run(L.blissgpu_analyze_batch, h_f32.data_ptr())),
+                    "f32_pageable_songs_per_sec": med3(lambda: run(L.blissgpu_analyze_batch, pageable.ctypes.data)),
+                    "s16_pinned_songs_per_sec": med3(lambda: run(L.blissgpu_analyze_batch_s16, h_s16.data_ptr())),
+                    "s16_pageable_songs_per_sec": med3(lambda: run(L.blissgpu_analyze_batch_s16, pageable_s16.ctypes.data))}
             feed["f32_pinned_GBps"] = round(feed["f32_pinned_songs_per_sec"] * N * 4 / 1e9, 2)
-            feed["note"] = "blissgpu_analyze_batch[_s16] from host memory: H2D of one group pipelined with the analysis of the previous"
+            feed["f32_pageable_over_pinned"] = round(feed["f32_pageable_songs_per_sec"] / feed["f32_pinned_songs_per_sec"], 3)
+            feed["s16_pageable_over_pinned"] = round(feed["s16_pageable_songs_per_sec"] / feed["s16_pinned_songs_per_sec"], 3)
+            feed["note"] = ("blissgpu_analyze_batch[_s16] from host memory: H2D of one group pipelined with the analysis of the previous; "
+                            "pageable = ordinary heap memory (what a Rust Vec<f32> is), staged by the library's pinned ring "
+                            "(staging_ring.hpp: worker threads fill page-locked slabs ahead of the link)")
             # what a decoder really delivers: 44.1 kHz stereo s16 (31.8 MB per 3-minute song); the device does FFmpegDecoder's
-            # conversion (libswresample to mono 22 050 Hz, bit for bit) in front of the analysis -- blissgpu_analyze_batch_decoded
+            # conversion (libswresample to mono 22 050 Hz, bit for bit at this rate) in front of the analysis -- blissgpu_analyze_batch_decoded
             hd = min(hf, 64)
             frames44 = 2 * N  # 3 minutes at 44.1 kHz -> N samples at 22 050 Hz
             h_44 = torch.empty(hd * frames44 * 2, dtype=torch.int16, pin_memory=True)
             h_44.random_(-20000, 20000)
-            songs44 = (_ffi.DecodedSong * hd)()
-            for i in range(hd):
-                songs44[i] = _ffi.DecodedSong(h_44.data_ptr() + i * frames44 * 4, frames44, 44100, 2, _ffi.SAMPLE_S16)
+            pageable_44 = h_44.numpy().copy()
             res44 = np.empty((hd, d), np.float32)
             st44 = np.empty(hd, np.int32)
 
-            def run44():
+            def run44(base):
+                songs44 = (_ffi.DecodedSong * hd)()
+                for i in range(hd):
+                    songs44[i] = _ffi.DecodedSong(base + i * frames44 * 4, frames44, 44100, 2, _ffi.SAMPLE_S16)
                 t0 = time.perf_counter()
                 _ffi.check(L.blissgpu_analyze_batch_decoded(songs44, hd, 2, res44.ctypes.data, st44.ctypes.data_as(C.POINTER(C.c_int32))))
                 return hd / (time.perf_counter() - t0)
 
-            run44()
             feed["decoded_44k1_stereo_s16_songs"] = hd
-            feed["decoded_44k1_stereo_s16_songs_per_sec"] = round(run44(), 1)
+            feed["decoded_44k1_stereo_s16_songs_per_sec"] = med3(lambda: run44(h_44.data_ptr()))
+            rows_pinned = res44.copy()
+            feed["decoded_44k1_stereo_s16_pageable_songs_per_sec"] = med3(lambda: run44(pageable_44.ctypes.data))
+            feed["decoded_44k1_stereo_s16_pageable_over_pinned"] = round(
+                feed["decoded_44k1_stereo_s16_pageable_songs_per_sec"] / feed["decoded_44k1_stereo_s16_songs_per_sec"], 3)
             feed["decoded_44k1_stereo_s16_GBps"] = round(feed["decoded_44k1_stereo_s16_songs_per_sec"] * frames44 * 4 / 1e9, 2)
+            feed["pageable_rows_bit_identical_to_pinned"] = bool(np.array_equal(rows_pinned.view(np.uint32), res44.view(np.uint32)))
             assert (st44 == 0).all() and np.isfinite(res44).all()
             return feed
 

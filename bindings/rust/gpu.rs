@@ -68,6 +68,11 @@ pub mod sys {
     pub const BLISSGPU_SAMPLE_S16: c_int = 1;
     pub const BLISSGPU_SAMPLE_S32: c_int = 2;
     pub const BLISSGPU_SAMPLE_RATE: u32 = 22050;
+    /// the pinned staging ring of the host PCM feed (a `Vec<f32>` is pageable memory): worker threads, 0 = off
+    pub const BLISSGPU_OPT_STAGE_LANES: c_int = 9;
+    pub const BLISSGPU_OPT_STAGE_SLAB_KIB: c_int = 10;
+    pub const BLISSGPU_OPT_STAGE_SLABS: c_int = 11;
+    pub const BLISSGPU_OPT_STAGE_NUMA: c_int = 12;
 
     /// One song as the decoder delivers it (host memory): `frames` frames of `channels` interleaved samples.
     #[repr(C)]
@@ -89,6 +94,9 @@ pub mod sys {
         pub fn blissgpu_default_device_count() -> c_int;
         pub fn blissgpu_default_device(k: c_int) -> c_int;
         pub fn blissgpu_default_device_batches(k: c_int) -> u64;
+        pub fn blissgpu_default_ctx(k: c_int, ctx: *mut *mut blissgpu_ctx) -> c_int;
+        pub fn blissgpu_ctx_set_option(ctx: *mut blissgpu_ctx, option: c_int, value: i64) -> c_int;
+        pub fn blissgpu_ctx_staged_bytes(ctx: *mut blissgpu_ctx) -> u64;
         pub fn blissgpu_set_single_song_timeout_ms(ms: i64) -> c_int;
         pub fn blissgpu_feature_count(features_version: u32) -> u32;
         pub fn blissgpu_feature_weights(features_version: u32, out: *mut f32) -> c_int;

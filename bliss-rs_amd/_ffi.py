@@ -19,6 +19,7 @@ METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_MAHALANOBIS = 0, 1, 2
 OPT_SERIAL, OPT_TAIL_MODE, OPT_PIPELINE_CHUNKS, OPT_CAND_BUDGET, OPT_ROLLOFF_EXACT_ALL, OPT_DEBUG_CHROMA, OPT_TAIL_SPLIT = 0, 1, 2, 3, 4, 5, 6
 OPT_STFT_SHAPE = 7
 OPT_FLUX_ORDER = 8
+OPT_STAGE_LANES, OPT_STAGE_SLAB_KIB, OPT_STAGE_SLABS, OPT_STAGE_NUMA = 9, 10, 11, 12
 
 _f32p = C.POINTER(C.c_float)
 _f64p = C.POINTER(C.c_double)
@@ -52,6 +53,8 @@ SIGNATURES = {
     "blissgpu_ctx_get_workspace_limit": (C.c_uint64, [_vp]),
     "blissgpu_ctx_synchronize": (C.c_int, [_vp]),
     "blissgpu_ctx_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
+    "blissgpu_ctx_staged_bytes": (C.c_uint64, [_vp]),
+    "blissgpu_default_ctx": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "blissgpu_default_device_count": (C.c_int, []),
     "blissgpu_default_device": (C.c_int, [C.c_int]),
     "blissgpu_default_device_batches": (C.c_uint64, [C.c_int]),

@@ -206,6 +206,11 @@ void default_ctx_count_batch(int k) {
 
 extern "C" {
 int blissgpu_default_device_count(void) { return default_ctx_count(); }
+int blissgpu_default_ctx(int k, blissgpu_ctx** ctx) {
+    if (!ctx) return fail(BLISSGPU_ERR_INVALID, "blissgpu_default_ctx", "NULL argument");
+    *ctx = nullptr;
+    return default_ctx_at(k, ctx);
+}
 int blissgpu_set_single_song_timeout_ms(int64_t ms) {
     // "never" (INT64_MAX) must not overflow the nanosecond clock the deadline is computed on: ten years is never
     constexpr int64_t TEN_YEARS_MS = 10LL * 365 * 24 * 3600 * 1000;
@@ -371,10 +376,20 @@ int blissgpu_ctx_set_option(blissgpu_ctx* c, int option, int64_t value) {
         case BLISSGPU_OPT_TAIL_SPLIT: c->tail_split = (int)value; break;
         case BLISSGPU_OPT_FLUX_ORDER: c->flux_order = value != 0; break;
         case BLISSGPU_OPT_STFT_SHAPE: c->stft_shape = (value >= 0 && value <= 3) ? (int)value : 0; break;
+        case BLISSGPU_OPT_STAGE_LANES: c->feed.stage_cfg.lanes = (int)std::max<int64_t>(0, std::min<int64_t>(value, bg::MAX_STAGE_LANES)); break;
+        case BLISSGPU_OPT_STAGE_SLAB_KIB: c->feed.stage_cfg.slab_bytes = (size_t)std::max<int64_t>(64, std::min<int64_t>(value, 65536)) << 10; break;
+        case BLISSGPU_OPT_STAGE_NUMA: c->feed.stage_numa = value != 0; break;
+        case BLISSGPU_OPT_STAGE_SLABS: c->feed.stage_cfg.slabs_per_lane = (int)std::max<int64_t>(1, std::min<int64_t>(value, 8)); break;
         case BLISSGPU_OPT_CAND_BUDGET: c->cand_budget = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 714)); break;
         default: return fail(BLISSGPU_ERR_INVALID, "blissgpu_ctx_set_option", "unknown option");
     }
     return BLISSGPU_OK;
+}
+
+uint64_t blissgpu_ctx_staged_bytes(blissgpu_ctx* c) {
+    if (!c) return 0;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    return c->feed.staged_bytes + (c->feed.ring ? c->feed.ring->bytes_staged() : 0);
 }
 
 int blissgpu_ctx_set_workspace_limit(blissgpu_ctx* c, uint64_t bytes) {

@@ -5,8 +5,10 @@
 //   node.hip       one process driving every GPU of the node (RCCL all-gather of the feature rows)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -14,6 +16,7 @@
 #include "../../include/blissgpu.h"
 #include "internal.hpp"
 #include "resample.hpp"
+#include "staging_ring.hpp"
 
 namespace bg {
 
@@ -92,14 +95,35 @@ struct ChunkSlot {
     Workspace ws{};
 };
 
-// Persistent staging of the host-pointer entry points (the PCM feed): two device PCM buffers (+ raw s16 / multi-channel
-// staging), two result buffers, two copy streams (songs alternate between them: one stream moves 54.5 GB/s from pinned
+// Persistent staging of the host-pointer entry points (the PCM feed): N_FEED_BUFFERS device PCM buffers (+ raw s16 / multi-channel
+// staging) and result buffers, two copy streams (songs alternate between them: one stream moves 54.5 GB/s from pinned
 // memory, two 57.3 -- tests/tools/probes/h2d_probe.hip) and the events that order them.  Grow-only; guarded by the
 // context mutex.
 #ifndef FEED_COPY_STREAMS
 #define FEED_COPY_STREAMS 2
 #endif
+// the staging ring's default shape (measured: tests/tools/stage_sweep.py, profiles/r06_stage_sweep.txt)
+#ifndef STAGE_LANES_DEFAULT
+#define STAGE_LANES_DEFAULT 4
+#endif
+#ifndef STAGE_SLABS_DEFAULT
+#define STAGE_SLABS_DEFAULT 3
+#endif
+#ifndef STAGE_SLAB_KIB_DEFAULT
+#define STAGE_SLAB_KIB_DEFAULT 4096
+#endif
+#ifndef STAGE_EVENT_FLAGS
+#define STAGE_EVENT_FLAGS (hipEventDisableTiming | hipEventBlockingSync)
+#endif
 constexpr int N_COPY_STREAMS = FEED_COPY_STREAMS;
+// Device staging buffers the groups of a call rotate through.  Three: group g + 2 is on the link while group g + 1 waits for
+// its turn and group g is analysed: slack for a group whose analysis takes as long as the next group's transfer (mono s16:
+// 33 songs cross the link in 5 ms and take 4 - 5 ms to analyse).  Against two buffers the difference is inside the spread of
+// the s16 line (profiles/r06_feed_buffers_ab.txt); the third costs device memory only.
+#ifndef FEED_BUFFERS
+#define FEED_BUFFERS 3
+#endif
+constexpr int N_FEED_BUFFERS = FEED_BUFFERS;
 // one song of the host PCM feed as the decoder delivers it
 constexpr uint32_t MAX_SAMPLE_RATE = 768000;  // the resample kernel's 64-bit stream positions hold for any song below this
 struct FeedSong {
@@ -117,12 +141,63 @@ struct ResampleBank {
     float* d_bank = nullptr;
 };
 
+// The device side of the pinned staging ring (staging_ring.hpp): page-locked slabs, one HIP stream per lane.
+constexpr int MAX_STAGE_LANES = 16;
+struct HipStageDev {
+    int device;
+    hipStream_t* streams;  // [MAX_STAGE_LANES], owned by the HostFeed
+    std::vector<int> cpus; // the CPUs next to the device (its PCIe root's NUMA node), or empty = wherever the scheduler likes
+    // A worker settles on the device's side of the machine before it allocates its slabs: on a two-socket host the slab the
+    // DMA engine reads, and the thread that fills it, then sit on the socket the GPU hangs off (page-locked memory is placed
+    // where the allocating thread runs) -- only the read of the caller's buffer may cross the socket link.
+    void thread_begin(int) {
+        (void)hipSetDevice(device);
+        if (!cpus.empty()) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            for (int cpu : cpus)
+                if (cpu >= 0 && cpu < CPU_SETSIZE) CPU_SET(cpu, &set);
+            (void)sched_setaffinity(0, sizeof(set), &set);  // (refused in a restricted cpuset: the worker stays where it is)
+        }
+    }
+    void* slab_alloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return p;
+    }
+    void slab_free(void* p) { (void)hipHostFree(p); }
+    void* event_create() {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, STAGE_EVENT_FLAGS) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return (void*)e;
+    }
+    void event_destroy(void* e) { (void)hipEventDestroy((hipEvent_t)e); }
+    int copy_async(void* dst, const void* slab, size_t bytes, int lane) {
+        return (int)hipMemcpyAsync(dst, slab, bytes, hipMemcpyHostToDevice, streams[lane]);
+    }
+    int event_record(void* ev, int lane) { return (int)hipEventRecord((hipEvent_t)ev, streams[lane]); }
+    int event_wait(void* ev) { return (int)hipEventSynchronize((hipEvent_t)ev); }
+    std::string error_string(int code) { return hipGetErrorString((hipError_t)code); }
+};
+
 struct HostFeed {
-    DevBuf<float> pcm[2];
-    DevBuf<uint8_t> raw[2];
-    DevBuf<float> out[2];
-    hipEvent_t ev_copied[2][N_COPY_STREAMS] = {}, ev_done[2] = {nullptr, nullptr};
+    DevBuf<float> pcm[N_FEED_BUFFERS];
+    DevBuf<uint8_t> raw[N_FEED_BUFFERS];
+    DevBuf<float> out[N_FEED_BUFFERS];
+    PinnedBuf<float> h_rows;  // (FEED_ROWS_STAGED builds only: the call's rows through a page-locked buffer, see scheduler.hip)
+    hipEvent_t ev_copied[N_FEED_BUFFERS][N_COPY_STREAMS] = {}, ev_done[N_FEED_BUFFERS] = {};
     hipStream_t copy_stream[N_COPY_STREAMS] = {};
+    // pageable sources (what a Rust Vec<f32> or a decoder's frame buffer is): staged by the library through page-locked slabs
+    // by worker threads that run ahead of the link -- see staging_ring.hpp.  Started on the first call that brings
+    // STAGE_MIN_BYTES of pageable PCM; BLISSGPU_OPT_STAGE_* change the shape (0 lanes = leave the staging to the HIP runtime).
+    StageConfig stage_cfg{STAGE_LANES_DEFAULT, STAGE_SLABS_DEFAULT, (size_t)STAGE_SLAB_KIB_DEFAULT << 10};
+    std::unique_ptr<StagingRing<HipStageDev>> ring;
+    hipStream_t lane_stream[MAX_STAGE_LANES] = {};
+    hipEvent_t ev_lane[N_FEED_BUFFERS][MAX_STAGE_LANES] = {};
+    bool stage_numa = false;    // BLISSGPU_OPT_STAGE_NUMA: the workers (and their slabs) live on the device's NUMA node
+    bool stage_numa_known = false;  // the placement the running ring was started with
+    uint64_t staged_calls = 0;  // host-feed calls that went through the ring (statistics)
+    uint64_t staged_bytes = 0;  // bytes staged by rings this context has had before the current one (a restart resets the ring's count)
 };
 
 }  // namespace bg
@@ -230,6 +305,10 @@ int analyze_host_songs(blissgpu_ctx* c, const void* const* ptrs, const uint64_t*
                        uint32_t channels, uint32_t features_version, float* out, int32_t* status, const char* who,
                        float* d_rows = nullptr, uint32_t sample_rate = SWR_OUT_RATE);
 int resample_bank(blissgpu_ctx* c, uint32_t rate, const ResampleBank** out, const char* who);
+// the CPUs local to a HIP device (sysfs local_cpulist of its PCI function); empty when the host has one node or does not say
+std::vector<int> device_local_cpus(int device);
+// "0-3,8,10-11" -> {0,1,2,3,8,10,11} (device-free: tests/cpp/test_staging.cpp)
+std::vector<int> parse_cpulist(const char* text);
 int enqueue_decode(blissgpu_ctx* c, const void* d_in, int fmt, uint32_t channels, uint64_t frames, uint32_t rate, float* d_out,
                    uint64_t n_out, hipStream_t st, const char* who);
 

@@ -339,12 +339,19 @@ void scheduler_release(blissgpu_ctx* c) {
         s = ChunkSlot{};
     }
     HostFeed& f = c->feed;
+    f.ring.reset();  // joins the staging workers, frees the slabs
+    for (hipStream_t& ls : f.lane_stream)
+        if (ls) { (void)hipStreamSynchronize(ls); (void)hipStreamDestroy(ls); ls = nullptr; }
+    for (auto& row : f.ev_lane)
+        for (hipEvent_t& ev : row)
+            if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
     for (auto& kv : c->swr_banks)
         if (kv.second.d_bank) (void)hipFree(kv.second.d_bank);
     c->swr_banks.clear();
     for (hipStream_t& cs : f.copy_stream)
         if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); cs = nullptr; }
-    for (int b = 0; b < 2; b++) {
+    f.h_rows.release();
+    for (int b = 0; b < N_FEED_BUFFERS; b++) {
         f.pcm[b].release(); f.raw[b].release(); f.out[b].release();
         for (hipEvent_t& ev : f.ev_copied[b])
             if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
@@ -363,6 +370,12 @@ void scheduler_release(blissgpu_ctx* c) {
 // ------------------------------------------------------------------------------------------------------------------
 #ifndef FEED_GROUP_MIB
 #define FEED_GROUP_MIB 512
+#endif
+#ifndef FEED_GROUP_PCM_FACTOR
+#define FEED_GROUP_PCM_FACTOR 1
+#endif
+#ifndef STAGE_MIN_BYTES
+#define STAGE_MIN_BYTES (8ull << 20)
 #endif
 // the filter bank of one input rate, built once per context (resample.hpp) and kept on the device
 int resample_bank(blissgpu_ctx* c, uint32_t rate, const ResampleBank** out, const char* who) {
@@ -383,6 +396,45 @@ int resample_bank(blissgpu_ctx* c, uint32_t rate, const ResampleBank** out, cons
     }
     *out = &it->second;
     return BLISSGPU_OK;
+}
+
+std::vector<int> parse_cpulist(const char* text) {
+    std::vector<int> cpus;
+    for (const char* p = text; p && *p;) {
+        char* end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p || a < 0) break;
+        long b = a;
+        if (*end == '-') {
+            const char* q = end + 1;
+            b = strtol(q, &end, 10);
+            if (end == q || b < a) break;
+        }
+        for (long v = a; v <= b && cpus.size() < 4096; v++) cpus.push_back((int)v);
+        p = *end == ',' ? end + 1 : end;
+        if (*end != ',') break;
+    }
+    return cpus;
+}
+
+std::vector<int> device_local_cpus(int device) {
+    char bus[32] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return {}; }
+    for (char* p = bus; *p; p++) *p = (char)tolower((unsigned char)*p);
+    const std::string base = std::string("/sys/bus/pci/devices/") + bus;
+    char line[4096] = {0};
+    int node = -1;
+    if (FILE* f = fopen((base + "/numa_node").c_str(), "r")) {
+        if (fgets(line, sizeof(line), f)) node = atoi(line);
+        fclose(f);
+    }
+    if (node < 0) return {};  // one node, or the platform does not say: leave the workers alone
+    std::vector<int> cpus;
+    if (FILE* f = fopen((base + "/local_cpulist").c_str(), "r")) {
+        if (fgets(line, sizeof(line), f)) cpus = parse_cpulist(line);
+        fclose(f);
+    }
+    return cpus;
 }
 
 // decoder output of one song (device) -> mono 22 050 Hz f32 (device), on `st`
@@ -429,32 +481,79 @@ int analyze_host_songs(blissgpu_ctx* c, const FeedSong* in, uint32_t n_songs, ui
     if (!f.copy_stream[N_COPY_STREAMS - 1]) {
         for (hipStream_t& cs : f.copy_stream)
             if (!cs) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < N_FEED_BUFFERS; b++) {
             for (hipEvent_t& ev : f.ev_copied[b])
                 if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             if (!f.ev_done[b]) HIP_TRY(hipEventCreateWithFlags(&f.ev_done[b], hipEventDisableTiming));
         }
     }
+    // Which sources are pageable?  Page-locked / registered / device memory goes to the copy streams as it is (the DMA engines
+    // read it directly); ordinary heap memory -- a Rust Vec<f32>, a decoder's frame buffer, a numpy array -- is staged through
+    // the ring's page-locked slabs by its worker threads (staging_ring.hpp).  A call that brings less than STAGE_MIN_BYTES of it
+    // is left to the runtime: a short song is one bounce buffer, and the single-song front should not wake six threads for it.
+    std::vector<uint8_t> pageable(n_songs, 0);
+    bool use_ring = false;
+    if (f.stage_cfg.lanes > 0) {
+        uint64_t pageable_bytes = 0;
+        for (uint32_t i = 0; i < n_songs; i++) {
+            if (!in[i].frames) continue;
+            hipPointerAttribute_t at;
+            const hipError_t pe = hipPointerGetAttributes(&at, in[i].p);
+            if (pe != hipSuccess) (void)hipGetLastError();  // (older runtimes report an unregistered pointer as an error)
+            pageable[i] = pe != hipSuccess || at.type == hipMemoryTypeUnregistered;
+            if (pageable[i]) pageable_bytes += in[i].frames * in[i].frame_bytes();
+        }
+        use_ring = pageable_bytes >= STAGE_MIN_BYTES;
+    }
+    if (use_ring) {
+        StageConfig want = f.stage_cfg;
+        want.lanes = std::min(want.lanes, MAX_STAGE_LANES);
+        for (int l = 0; l < want.lanes; l++) {
+            if (!f.lane_stream[l]) HIP_TRY(hipStreamCreateWithFlags(&f.lane_stream[l], hipStreamNonBlocking));
+            for (int b = 0; b < N_FEED_BUFFERS; b++)
+                if (!f.ev_lane[b][l]) HIP_TRY(hipEventCreateWithFlags(&f.ev_lane[b][l], hipEventDisableTiming));
+        }
+        if (!f.ring) f.ring.reset(new StagingRing<HipStageDev>(HipStageDev{c->device, f.lane_stream, {}}));
+        if (!f.ring->running() || !(f.ring->config() == want) || f.stage_numa_known != f.stage_numa) {
+            f.ring->stop();
+            f.ring->dev().cpus = f.stage_numa ? device_local_cpus(c->device) : std::vector<int>{};
+            f.stage_numa_known = f.stage_numa;
+            std::string why;
+            f.staged_bytes += f.ring->bytes_staged();
+            if (!f.ring->start(want, &why)) use_ring = false;  // no page-locked memory to be had: the runtime's own staging still works
+        }
+    }
+    if (use_ring) f.staged_calls++;
+    else std::fill(pageable.begin(), pageable.end(), 0);
+    const int n_lanes = use_ring ? f.ring->config().lanes : 0;
+    const size_t slab_bytes = use_ring ? f.ring->config().slab_bytes : 0;
+
     // groups of <= 512 MiB of staging (mono f32: ~32 three-minute songs).  The transfer is the bottleneck (a group's
     // analysis takes a tenth of its transfer time), so what a call pays beyond its bytes is the analysis of the LAST group:
     // small groups keep that tail short, and 32 songs still fill the GPU several times over.  The cap is in BYTES of the
     // wider of the two buffers of a group (raw decoder output / mono f32), so an 8-channel f32 batch stages
     // 2 x 512 MiB like a mono one instead of 2 x 4 GiB.
     const uint64_t group_cap = (uint64_t)FEED_GROUP_MIB << 20;  // bytes
-    struct Group { uint32_t i0, n; std::vector<uint64_t> doff, dlen, roff; uint64_t total, raw_total; };
+    struct Group { uint32_t i0, n; std::vector<uint64_t> doff, dlen, roff; uint64_t total, raw_total, link_total; };
     std::vector<Group> groups;
     for (uint32_t i0 = 0; i0 < n_songs;) {
-        Group g{i0, 0, {}, {}, {}, 0, 0};
+        Group g{i0, 0, {}, {}, {}, 0, 0, 0};
         uint32_t i1 = i0;
         while (i1 < n_songs) {
             const uint64_t raw = in[i1].direct() ? 0 : (in[i1].frames + 63) / 64 * 64 * in[i1].frame_bytes();  // padded like the PCM
             const uint64_t pcm = (out_len[i1] + 63) / 64 * 64;
-            if (i1 > i0 && (4 * (g.total + pcm) > group_cap || g.raw_total + raw > group_cap)) break;
+            const uint64_t link = in[i1].direct() ? 4 * pcm : raw;  // what crosses the link for this song
+            // (FEED_GROUP_PCM_FACTOR = 2 lets a group of mono s16 songs be as long on the LINK as a group of f32 songs -- 66
+            // songs, 10 ms -- instead of 33 songs whose 5 ms transfer barely covers the 4 - 5 ms a batch that small takes to
+            // analyse, profiles/r06_feed_trace_s16.txt.  Measured: no gain from pageable memory and a longer tail from
+            // page-locked memory, profiles/r06_feed_group_rule_ab.txt; the cap stays on the wider buffer.)
+            if (i1 > i0 && (g.link_total + link > group_cap || 4 * (g.total + pcm) > FEED_GROUP_PCM_FACTOR * group_cap || g.raw_total + raw > group_cap)) break;
             g.doff.push_back(g.total);
             g.dlen.push_back(out_len[i1]);
             g.roff.push_back(g.raw_total);
             g.total += pcm;
             g.raw_total += raw;
+            g.link_total += link;
             i1++;
         }
         g.n = i1 - i0;
@@ -467,44 +566,91 @@ int analyze_host_songs(blissgpu_ctx* c, const FeedSong* in, uint32_t n_songs, ui
         max_raw = std::max(max_raw, g.raw_total);
         max_n = std::max<uint64_t>(max_n, g.n);
     }
-    const int nbuf = groups.size() > 1 ? 2 : 1;
+    const int nbuf = (int)std::min<size_t>(groups.size(), (size_t)N_FEED_BUFFERS);
     int rc = BLISSGPU_OK;
     for (int b = 0; b < nbuf && !rc; b++) {
         rc = f.pcm[b].ensure(max_total);
         if (!rc && any_raw) rc = f.raw[b].ensure(max_raw + 256);
         if (!rc) rc = f.out[b].ensure(max_n * d);
     }
+#ifdef FEED_ROWS_STAGED
+    if (!rc) rc = f.h_rows.ensure((size_t)n_songs * d);
+#endif
     if (rc) return rc;
 
-    auto upload = [&](size_t gi) -> hipError_t {  // H2D of group gi into buffer gi % nbuf, on the copy stream
+    std::vector<uint64_t> ticket(groups.size(), 0);
+    auto upload = [&](size_t gi) -> hipError_t {  // H2D of group gi into buffer gi % nbuf
         const Group& g = groups[gi];
         const int b = (int)(gi % nbuf);
         // buffer b is free again once the analysis that last read it (this call's group gi - 2, or an earlier call:
         // every call ends synchronised) has finished
+        const bool wait_free = gi >= (size_t)nbuf;
         hipError_t ee = hipSuccess;
-        for (int q = 0; q < N_COPY_STREAMS && ee == hipSuccess && gi >= (size_t)nbuf; q++)
+        for (int q = 0; q < N_COPY_STREAMS && ee == hipSuccess && wait_free; q++)
             ee = hipStreamWaitEvent(f.copy_stream[q], f.ev_done[b], 0);
+        std::vector<StagePiece> pieces;
         for (uint32_t k = 0; k < g.n && ee == hipSuccess; k++) {
             const FeedSong& fs = in[g.i0 + k];
-            if (fs.frames) {
-                void* dst = fs.direct() ? (void*)(f.pcm[b].p + g.doff[k]) : (void*)(f.raw[b].p + g.roff[k]);
-                ee = hipMemcpyAsync(dst, fs.p, fs.frames * fs.frame_bytes(), hipMemcpyHostToDevice,
-                                    f.copy_stream[k % N_COPY_STREAMS]);
+            if (!fs.frames) continue;
+            uint8_t* dst = fs.direct() ? (uint8_t*)(f.pcm[b].p + g.doff[k]) : f.raw[b].p + g.roff[k];
+            const size_t bytes = fs.frames * fs.frame_bytes();
+            if (pageable[g.i0 + k]) {  // through the ring, a slab at a time, on the workers' lanes
+                for (size_t off = 0; off < bytes; off += slab_bytes)
+                    pieces.push_back(StagePiece{(const uint8_t*)fs.p + off, dst + off, std::min(slab_bytes, bytes - off)});
+            } else {
+                ee = hipMemcpyAsync(dst, fs.p, bytes, hipMemcpyHostToDevice, f.copy_stream[k % N_COPY_STREAMS]);
             }
         }
         for (int q = 0; q < N_COPY_STREAMS && ee == hipSuccess; q++) ee = hipEventRecord(f.ev_copied[b][q], f.copy_stream[q]);
+        if (use_ring && ee == hipSuccess) {
+            hipEvent_t ev_free = f.ev_done[b];
+            hipStream_t* ls = f.lane_stream;
+            hipEvent_t* ev_in = f.ev_lane[b];
+            ticket[gi] = f.ring->post(
+                std::move(pieces),
+                [=](int lane) { return wait_free ? (int)hipStreamWaitEvent(ls[lane], ev_free, 0) : 0; },
+                [=](int lane) { return (int)hipEventRecord(ev_in[lane], ls[lane]); });
+        }
         return ee;
     };
+    // every exit: no worker still reads the caller's memory, no lane still writes the staging buffers
+    auto settle = [&]() -> hipError_t {
+        hipError_t es = hipSuccess;
+        if (use_ring) {
+            std::string why;
+            const int re = f.ring->drain(&why);
+            if (re) es = (hipError_t)re;
+            for (int l = 0; l < n_lanes; l++) {
+                const hipError_t eq = hipStreamSynchronize(f.lane_stream[l]);
+                if (es == hipSuccess) es = eq;
+            }
+        }
+        return es;
+    };
 
-    hipError_t e = upload(0);
+    // BLISSGPU_FEED_TRACE=1 (developer aid): the host-side timeline of the call, group by group, on stderr
+    static const bool trace = getenv("BLISSGPU_FEED_TRACE") != nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+    hipError_t e = hipSuccess;
+    size_t posted = 0;
     for (size_t gi = 0; gi < groups.size() && e == hipSuccess && !rc; gi++) {
+        const double t_iter = ms_now();
         const Group& g = groups[gi];
         const int b = (int)(gi % nbuf);
-        // The next group's transfer is queued BEFORE this group's analysis is enqueued (its buffer was released by the
-        // event group gi - 1 recorded): enqueuing an analysis can block the host on an earlier chunk's events, and the
-        // link must not run dry meanwhile.  (Pageable sources block the host here, not the GPU.)
-        if (gi + 1 < groups.size()) e = upload(gi + 1);
+        // The transfers of the next nbuf - 1 groups are queued BEFORE this group's analysis is enqueued (the buffer of group
+        // gi + nbuf - 1 was released by the event group gi - 1 recorded): enqueuing an analysis can block the host on an
+        // earlier chunk's events, and the link must not run dry meanwhile.
+        while (posted < groups.size() && posted < gi + (size_t)nbuf && e == hipSuccess) e = upload(posted++);
         for (int q = 0; q < N_COPY_STREAMS && e == hipSuccess; q++) e = hipStreamWaitEvent(c->stream, f.ev_copied[b][q], 0);
+        if (use_ring && e == hipSuccess) {
+            // the workers have queued every slab of this group on their lanes (they are already filling the next group's)
+            std::string why;
+            const int re = f.ring->wait_enqueued(ticket[gi], &why);
+            if (re) { (void)settle(); (void)hipStreamSynchronize(c->stream); return fail(BLISSGPU_ERR_HIP, who, why.c_str()); }
+            for (int l = 0; l < n_lanes && e == hipSuccess; l++) e = hipStreamWaitEvent(c->stream, f.ev_lane[b][l], 0);
+        }
+        const double t_staged = ms_now();
         if (e != hipSuccess) break;
         // widening / downmix / resampling on the device.  A group of one format at 22 050 Hz (the bulk case: s16 from the
         // decoder) is ONE launch over the whole staging area -- its songs are packed with the same 64-frame padding in both
@@ -529,24 +675,39 @@ int analyze_host_songs(blissgpu_ctx* c, const FeedSong* in, uint32_t n_songs, ui
         if (e != hipSuccess || rc) break;
         rc = blissgpu_analyze_batch_device(c, f.pcm[b].p, g.doff.data(), g.dlen.data(), g.n, features_version, f.out[b].p, nullptr);
         if (rc) break;
+        const double t_enq = ms_now();
+        // (The rows go straight into the caller's array.  Through a page-locked buffer of the context the calling thread would
+        // not be held here until the group's analysis has finished -- and the feed measured 5 - 10 % SLOWER that way:
+        // FEED_ROWS_STAGED, profiles/r06_feed_rows_ab.txt.)
+#ifdef FEED_ROWS_STAGED
+        e = hipMemcpyAsync(f.h_rows.p + (size_t)g.i0 * d, f.out[b].p, (size_t)g.n * d * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+#else
         e = hipMemcpyAsync(out + (size_t)g.i0 * d, f.out[b].p, (size_t)g.n * d * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+#endif
         if (e == hipSuccess && d_rows)
             e = hipMemcpyAsync(d_rows + (size_t)g.i0 * d, f.out[b].p, (size_t)g.n * d * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
         if (e == hipSuccess) e = hipEventRecord(f.ev_done[b], c->stream);
+        if (trace)
+            fprintf(stderr, "feed group %zu/%zu (%u songs, buffer %d): iteration at %.2f ms, staged %.2f, analysis enqueued %.2f, rows requested %.2f\n",
+                    gi, groups.size(), g.n, b, t_iter, t_staged, t_enq, ms_now());
         if (status)
             for (uint32_t k = 0; k < g.n; k++)
                 status[g.i0 + k] = g.dlen[k] >= (uint64_t)MIN_SAMPLES ? BLISSGPU_SONG_OK : BLISSGPU_SONG_TOO_SHORT;
     }
     // every exit leaves the streams drained: the staging buffers belong to the next call
-    hipError_t e1 = hipSuccess;
+    hipError_t e1 = settle();
     for (hipStream_t cs : f.copy_stream) {
         const hipError_t eq = hipStreamSynchronize(cs);
         if (e1 == hipSuccess) e1 = eq;
     }
     const hipError_t e2 = hipStreamSynchronize(c->stream);
+    if (trace) fprintf(stderr, "feed call done at %.2f ms (%s)\n", ms_now(), use_ring ? "ring" : "direct");
     if (rc) return rc;
     if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
     if (e != hipSuccess) return fail(BLISSGPU_ERR_HIP, who, hipGetErrorString(e));
+#ifdef FEED_ROWS_STAGED
+    memcpy(out, f.h_rows.p, (size_t)n_songs * d * sizeof(float));
+#endif
     return BLISSGPU_OK;
 }
 

@@ -30,6 +30,26 @@ class Context:
         if use_torch_stream:
             self.bind_current_stream()
 
+    @classmethod
+    def default(cls, k: int = 0) -> "Context":
+        """The k-th default context of the library -- the one the entry points without a context argument run on
+        (blissgpu_default_ctx).  Borrowed: closing this object leaves the context alone."""
+        import torch
+
+        self = cls.__new__(cls)
+        self.torch = torch
+        self._L = _ffi.lib()
+        h = C.c_void_p()
+        _ffi.check(self._L.blissgpu_default_ctx(int(k), C.byref(h)))
+        self._h = h
+        self._borrowed = True
+        self.device = self._L.blissgpu_default_device(int(k))
+        return self
+
+    def staged_bytes(self) -> int:
+        """Bytes of pageable host PCM staged through this context's pinned ring so far (blissgpu_ctx_staged_bytes)."""
+        return int(self._L.blissgpu_ctx_staged_bytes(self._h))
+
     def bind_current_stream(self):
         """Launch on torch's current stream when it is a real stream; the legacy default stream (handle 0) cannot be
         adopted (NULL means "the context's own stream"), so in that case every call below is ordered against it with
@@ -50,7 +70,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.blissgpu_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._L.blissgpu_ctx_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -61,7 +82,9 @@ class Context:
     OPTIONS = {"serial": _ffi.OPT_SERIAL, "tail_mode": _ffi.OPT_TAIL_MODE, "pipeline_chunks": _ffi.OPT_PIPELINE_CHUNKS,
                "cand_budget": _ffi.OPT_CAND_BUDGET, "rolloff_exact_all": _ffi.OPT_ROLLOFF_EXACT_ALL,
                "debug_chroma": _ffi.OPT_DEBUG_CHROMA, "tail_split": _ffi.OPT_TAIL_SPLIT,
-               "stft_shape": _ffi.OPT_STFT_SHAPE, "flux_order": _ffi.OPT_FLUX_ORDER}
+               "stft_shape": _ffi.OPT_STFT_SHAPE, "flux_order": _ffi.OPT_FLUX_ORDER,
+               "stage_lanes": _ffi.OPT_STAGE_LANES, "stage_slab_kib": _ffi.OPT_STAGE_SLAB_KIB, "stage_slabs": _ffi.OPT_STAGE_SLABS,
+               "stage_numa": _ffi.OPT_STAGE_NUMA}
 
     def set_option(self, name: str, value: int):
         """Scheduling knobs for the measurement tools and the tests (blissgpu_ctx_set_option)."""

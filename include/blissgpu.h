@@ -109,13 +109,34 @@ int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
 #define BLISSGPU_OPT_DEBUG_CHROMA 5     /* 1: the contraction also keeps chroma_stft's matrix and the assembly the interval
                                            means of the chunk for the CHROMA / INTERVAL taps below (96 B per frame); such a
                                            batch must fit ONE chunk (BLISSGPU_ERR_INVALID otherwise) */
+/* The host PCM feed's pinned staging ring (pageable sources -- a Rust Vec<f32> out of PreAnalyzedSong,
+ * src/song/decoder.rs:34-65, a decoder's frame buffers -- are copied into page-locked slabs by worker threads that run ahead
+ * of the link; page-locked / registered sources are handed to the DMA engines as they are).  The ring restarts with the new
+ * shape on the next host-pointer call. */
+#define BLISSGPU_OPT_STAGE_LANES 9      /* worker threads = copy queues, 1..16; 0 = no ring: leave the staging of pageable memory
+                                           to the HIP runtime (one bounce buffer on the calling thread).  Default 4 */
+#define BLISSGPU_OPT_STAGE_SLAB_KIB 10  /* size of one page-locked slab, 64 .. 65536 KiB.  Default 4096 */
+#define BLISSGPU_OPT_STAGE_SLABS 11     /* slabs each worker rotates through, 1..8.  Default 3 (4 x 3 x 4 MiB = 48 MiB per context) */
+#define BLISSGPU_OPT_STAGE_NUMA 12      /* 1: the workers run, and allocate their slabs, on the CPUs next to the device (sysfs
+                                           local_cpulist of its PCI function; a no-op on a one-node host); 0 (default): wherever
+                                           the scheduler puts them -- near the caller's buffers, which measured better: a worker
+                                           reading the caller's memory across the socket link is slower than the DMA engine
+                                           reading the slab across it (profiles/r06_stage_sweep.txt) */
 int blissgpu_ctx_set_option(blissgpu_ctx *ctx, int option, int64_t value);
+/* Bytes of pageable host PCM this context has staged through its pinned ring since it was created (0: every source so far
+ * was page-locked, small, or the ring is switched off). */
+uint64_t blissgpu_ctx_staged_bytes(blissgpu_ctx *ctx);
 
 /* The default contexts: how many there are, the HIP ordinal of the k-th, and how many coalesced batches of single-song
  * calls it has served so far (load statistics). */
 int blissgpu_default_device_count(void);
 int blissgpu_default_device(int k);
 uint64_t blissgpu_default_device_batches(int k);
+/* The k-th default context itself -- the one the entry points WITHOUT a context argument run on (k = 0 serves the batch,
+ * distance and playlist forms; every k a seat of the single-song front) -- created now if it does not exist yet.  Borrowed:
+ * the library owns it (never pass it to blissgpu_ctx_destroy); use it for blissgpu_ctx_set_option (e.g. the staging ring's
+ * shape), the workspace limit, the profile / debug taps. */
+int blissgpu_default_ctx(int k, blissgpu_ctx **ctx);
 /* How long a single-song call (blissgpu_analyze / _interleaved) may wait for a default context to pick it up before it
  * fails with BLISSGPU_ERR_TIMEOUT instead of blocking (default 600 000 ms; <= 0 restores the default; clamped to ten
  * years).  A default context

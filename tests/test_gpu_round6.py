@@ -1,0 +1,227 @@
+"""GPU tests of round 6 (-m gpu).
+
+Row f1, first clause ("decoder output -> pinned host staging -> H2D double-buffering"), for memory the caller did NOT pin: a
+Rust Vec<f32> out of PreAnalyzedSong (src/song/decoder.rs:34-65, 85-101), FFmpeg's frame buffers
+(src/song/decoder/ffmpeg.rs:36-109), a numpy array -- ordinary pageable heap memory -- goes through the library's pinned
+staging ring (bliss-rs_amd/csrc/staging_ring.hpp).  Whatever the source memory and the ring's shape, the rows must be the same
+bits: the ring only moves bytes.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GROUP_BYTES = 512 << 20  # FEED_GROUP_MIB of scheduler.hip
+
+
+@pytest.fixture(scope="module")
+def bliss():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import bliss_rs_amd
+
+    return bliss_rs_amd
+
+
+@pytest.fixture(scope="module")
+def dctx(bliss):
+    """the default context the host-pointer batch entry points run on (borrowed)"""
+    c = bliss.Context.default(0)
+    yield c
+    _default_shape(c)
+
+
+def _default_shape(dctx):
+    for k, v in (("stage_lanes", 4), ("stage_slab_kib", 4096), ("stage_slabs", 3), ("stage_numa", 0)):
+        dctx.set_option(k, v)
+
+
+def _mixed_library(rng, n_songs):
+    """What decoders deliver: 44.1 kHz stereo s16 (most files), 48 kHz mono s32, 22 050 Hz mono f32 / s16; one to three and a
+    half minutes; one song too short."""
+    songs = []
+    for i in range(n_songs):
+        kind = i % 4
+        secs = float(rng.uniform(60, 210))
+        if i == 5:
+            secs = 0.2
+        if kind in (0, 1):
+            n = int(secs * 44100)
+            a = rng.integers(-20000, 20000, (n, 2), dtype=np.int16)
+            songs.append((a, 44100))
+        elif kind == 2:
+            n = int(secs * 48000)
+            a = (rng.integers(-2**30, 2**30, n, dtype=np.int64)).astype(np.int32)
+            songs.append((a, 48000))
+        else:
+            n = int(secs * 22050)
+            a = (rng.random(n, np.float32) - np.float32(0.5)) if i % 8 == 3 else rng.integers(-20000, 20000, n, dtype=np.int16)
+            songs.append((a, 22050))
+    return songs
+
+
+def _fmt(a):
+    from bliss_rs_amd import _ffi
+
+    return {np.dtype(np.float32): _ffi.SAMPLE_F32, np.dtype(np.int16): _ffi.SAMPLE_S16, np.dtype(np.int32): _ffi.SAMPLE_S32}[a.dtype]
+
+
+def _run_decoded(ptrs, songs, version=2):
+    from bliss_rs_amd import _ffi
+
+    L = _ffi.lib()
+    n = len(songs)
+    arr = (_ffi.DecodedSong * n)()
+    for i, ((a, rate), p) in enumerate(zip(songs, ptrs)):
+        arr[i] = _ffi.DecodedSong(p, a.shape[0], rate, 1 if a.ndim == 1 else a.shape[1], _fmt(a))
+    d = 23 if version == 2 else 20
+    out = np.full((n, d), np.nan, np.float32)
+    st = np.full(n, -1, np.int32)
+    _ffi.check(L.blissgpu_analyze_batch_decoded(arr, n, version, out.ctypes.data, st.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out, st
+
+
+def test_pageable_pinned_and_device_sources_give_identical_rows(bliss, dctx):
+    """A mixed-format library that spans >= 3 staging groups, from (a) pageable heap memory through the ring, (b) page-locked
+    copies straight to the DMA engines, (c) a mix of both in one call, (d) already on the device (conversion + analysis through
+    the device entry points): the same rows bit for bit, and the ring did move (a)'s bytes."""
+    import torch
+
+    _default_shape(dctx)
+    rng = np.random.default_rng(606)
+    songs = _mixed_library(rng, 64)
+    raw_bytes = sum(a.nbytes for a, _ in songs)
+    assert raw_bytes > 2.2 * GROUP_BYTES, raw_bytes  # >= 3 groups of <= 512 MiB
+    before = dctx.staged_bytes()
+    rows_a, st_a = _run_decoded([a.ctypes.data for a, _ in songs], songs)
+    staged = dctx.staged_bytes() - before
+    assert staged == raw_bytes, (staged, raw_bytes)  # every byte of the call went through the slabs, once
+    assert st_a[5] == 1 and (np.delete(st_a, 5) == 0).all()
+    pinned = [torch.from_numpy(a).pin_memory() for a, _ in songs]
+    before = dctx.staged_bytes()
+    rows_b, st_b = _run_decoded([t.data_ptr() for t in pinned], songs)
+    assert dctx.staged_bytes() == before  # page-locked sources never touch the ring
+    assert np.array_equal(st_a, st_b)
+    ok = st_a == 0
+    assert np.array_equal(rows_a[ok].view(np.uint32), rows_b[ok].view(np.uint32))
+    # (c) every other song page-locked
+    ptrs = [pinned[i].data_ptr() if i % 2 else songs[i][0].ctypes.data for i in range(len(songs))]
+    before = dctx.staged_bytes()
+    rows_c, st_c = _run_decoded(ptrs, songs)
+    assert dctx.staged_bytes() - before == sum(a.nbytes for i, (a, _) in enumerate(songs) if i % 2 == 0)
+    assert np.array_equal(st_a, st_c) and np.array_equal(rows_a[ok].view(np.uint32), rows_c[ok].view(np.uint32))
+    # (d) device-resident: decode each song on the device, analyse the batch there
+    ctx = bliss.Context(0)
+    try:
+        mono = [ctx.pcm_decode(t.cuda(), rate) for t, (_, rate) in zip(pinned, songs)]
+        lens = [int(m.numel()) for m in mono]
+        pad = [(n + 63) // 64 * 64 for n in lens]
+        offs = np.concatenate([[0], np.cumsum(pad)[:-1]]).astype(np.uint64)
+        pcm = torch.zeros(int(sum(pad)) + 64, dtype=torch.float32, device="cuda")
+        for o, m in zip(offs, mono):
+            pcm[int(o): int(o) + m.numel()] = m
+        out, status = ctx.analyze(pcm, offs, lens)
+        ctx.synchronize()
+        assert np.array_equal(status.cpu().numpy(), st_a)
+        assert np.array_equal(out.cpu().numpy()[ok].view(np.uint32), rows_a[ok].view(np.uint32))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 64, 0), (3, 2, 1000, 1), (16, 8, 256, 0), (2, 3, 65536, 1), (0, 3, 4096, 0)])
+def test_ring_shape_does_not_change_a_bit(bliss, dctx, shape):
+    """1 lane x 1 slab of 64 KiB (every slab reused at once), odd slab sizes, 16 lanes, slabs larger than a song, workers held
+    on the device's NUMA node or not, and the ring switched off (the HIP runtime's own staging): the same rows."""
+    from bliss_rs_amd import _ffi
+
+    rng = np.random.default_rng(7)
+    N = 1_500_000
+    n = 12
+    pcm = (rng.random(n * N, np.float32) - np.float32(0.5))
+    s16 = rng.integers(-30000, 30000, n * N, dtype=np.int16)
+    offs = (np.arange(n, dtype=np.uint64) * np.uint64(N))
+    lens = np.full(n, N, np.uint64)
+    lens[3] = 5000  # too short
+    L = _ffi.lib()
+
+    def run(fn, buf):
+        out = np.full((n, 23), np.nan, np.float32)
+        st = np.full(n, -1, np.int32)
+        _ffi.check(fn(buf.ctypes.data, offs.ctypes.data_as(C.POINTER(C.c_uint64)), lens.ctypes.data_as(C.POINTER(C.c_uint64)), n, 2,
+                      out.ctypes.data, st.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out, st
+
+    _default_shape(dctx)
+    ref_f, st_f = run(L.blissgpu_analyze_batch, pcm)
+    ref_s, st_s = run(L.blissgpu_analyze_batch_s16, s16)
+    lanes, slabs, kib, numa = shape
+    dctx.set_option("stage_numa", numa)
+    dctx.set_option("stage_lanes", lanes)
+    dctx.set_option("stage_slabs", slabs)
+    dctx.set_option("stage_slab_kib", kib)
+    before = dctx.staged_bytes()
+    got_f, gst_f = run(L.blissgpu_analyze_batch, pcm)
+    got_s, gst_s = run(L.blissgpu_analyze_batch_s16, s16)
+    moved = dctx.staged_bytes() - before
+    assert moved == (0 if lanes == 0 else int(lens.sum()) * 6), (moved, shape)
+    ok = st_f == 0
+    assert st_f[3] == 1 and np.array_equal(st_f, gst_f) and np.array_equal(st_s, gst_s)
+    assert np.array_equal(ref_f[ok].view(np.uint32), got_f[ok].view(np.uint32))
+    assert np.array_equal(ref_s[ok].view(np.uint32), got_s[ok].view(np.uint32))
+
+
+def test_small_pageable_calls_stay_off_the_ring(bliss, dctx):
+    """Less than 8 MiB of pageable PCM in a call (a lone short song through the single-song front) is left to the runtime's
+    bounce buffer: no worker is woken for it."""
+    _default_shape(dctx)
+    rng = np.random.default_rng(1)
+    x = (rng.random(10 * 22050, np.float32) - np.float32(0.5))
+    before = dctx.staged_bytes()
+    a = bliss.Song.analyze(x)
+    assert dctx.staged_bytes() == before
+    assert np.isfinite(a.as_arr1()).all()
+
+
+def test_threads_calling_the_single_song_entry_point_with_heap_buffers(bliss, dctx):
+    """The reference's worker pool (src/song/decoder.rs:299-329): threads each analysing their own freshly decoded Vec<f32>.
+    The front coalesces them into batches whose pageable songs go through the ring; every thread gets its own song's row."""
+    from bliss_rs_amd import _ffi
+
+    L = _ffi.lib()
+    _default_shape(dctx)
+    rng = np.random.default_rng(3)
+    T, per = 8, 3
+    N = 3 * 60 * 22050
+    songs = [(rng.random(N, np.float32) - np.float32(0.5)) for _ in range(T * per)]
+    rows = np.zeros((T * per, 23), np.float32)
+    errs = []
+
+    def work(t):
+        for k in range(per):
+            i = t * per + k
+            st = C.c_int32(-1)
+            rc = L.blissgpu_analyze(songs[i].ctypes.data, N, 2, rows[i].ctypes.data, C.byref(st))
+            if rc or st.value:
+                errs.append((i, rc, st.value))
+
+    before = dctx.staged_bytes()
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert dctx.staged_bytes() - before == T * per * N * 4
+    # the same songs as one batch from page-locked memory
+    import torch
+
+    flat = torch.from_numpy(np.concatenate(songs)).pin_memory()
+    offs = np.arange(T * per, dtype=np.uint64) * np.uint64(N)
+    lens = np.full(T * per, N, np.uint64)
+    ref = np.zeros_like(rows)
+    st = np.zeros(T * per, np.int32)
+    _ffi.check(L.blissgpu_analyze_batch(flat.data_ptr(), offs.ctypes.data_as(C.POINTER(C.c_uint64)), lens.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                        T * per, 2, ref.ctypes.data, st.ctypes.data_as(C.POINTER(C.c_int32))))
+    assert np.array_equal(rows.view(np.uint32), ref.view(np.uint32))

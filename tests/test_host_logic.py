@@ -327,6 +327,33 @@ def test_coalescing_front_under_thread_sanitizer(tmp_path):
         assert "bad 0" in out.stdout
 
 
+def test_staging_ring_on_the_cpu(tmp_path):
+    """The pinned staging ring of the host PCM feed (bliss-rs_amd/csrc/staging_ring.hpp) is device-free: against a stand-in
+    device whose copy queues execute LATER (a slab refilled before its copy completed corrupts the destination) every byte
+    of every transfer arrives, begin / end run once per lane and transfer, an injected copy error comes back from the
+    transfer it hit and the next one is clean, drain() covers the error paths, a restart with another shape leaks nothing.
+    Several shapes incl. one lane with one slab (every piece waits for the previous copy)."""
+    exe = tmp_path / "test_staging"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_staging.cpp"), "-o", str(exe)])
+    for args in (["80", "4", "3", "16", "1"], ["80", "1", "1", "4", "2"], ["120", "8", "2", "8", "3"], ["40", "16", "8", "64", "4"]):
+        out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and "staging ring ok" in out.stdout, (args, out.stdout + out.stderr)
+
+
+@pytest.mark.skipif(not os.path.exists(TSAN_CXX), reason="needs the ROCm clang for -fsanitize=thread")
+def test_staging_ring_under_thread_sanitizer(tmp_path):
+    """The same test with -fsanitize=thread: the workers, the poster and the stand-in copy engines share the transfer queue,
+    the slabs and their events without a data race."""
+    exe = tmp_path / "test_staging_tsan"
+    subprocess.check_call([TSAN_CXX, "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=thread",
+                           os.path.join(ROOT, "tests", "cpp", "test_staging.cpp"), "-o", str(exe)])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    for args in (["60", "4", "3", "16", "5"], ["60", "1", "1", "4", "6"], ["60", "7", "2", "64", "7"]):
+        out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, (args, out.stdout[-1500:], out.stderr[-3000:])
+        assert "ThreadSanitizer" not in out.stderr, (args, out.stderr[-3000:])
+
+
 def test_rolloff_guard_on_emulated_summation_orders():
     """The FFT-512 kernel counts the rolloff bins in its own summation order and proves, per frame, that the reference's
     sequential order (src/aubio.rs:36-58) gives the same count -- or hands the frame to the exact pass (kernels_fft512.hip,
