@@ -252,8 +252,22 @@ inline std::vector<BlissResult<Analysis>> analyze_decoded_batch(const std::vecto
 }
 
 // ---- CUE tracks as slices of one decoded buffer: BlissCueFile::get_songs (src/cue.rs:205-246) ----
+// An INDEX time as the `std::time::Duration` the sheet parser (rcue in the reference) hands to BlissCueFile.
+struct CueIndex {
+    uint64_t secs;
+    uint32_t nanos;
+    // `Duration::as_secs_f32`: (secs as f32) + (nanos as f32) / 1e9_f32 -- NOT the exact sum rounded once: the two differ in the
+    // last bit for 72 of the 360 000 mm:ss:ff values of an 80-minute disc, and the sample index derived from it moves by one
+    float as_secs_f32() const {
+        const volatile float q = static_cast<float>(nanos) / 1e9f;  // (rounded before the add, whatever the contraction mode)
+        return static_cast<float>(secs) + q;
+    }
+    // mm:ss:ff of the sheet (75 frames per second), integer nanoseconds truncated
+    static CueIndex from_msf(uint64_t mm, uint64_t ss, uint64_t ff) { return {mm * 60 + ss, static_cast<uint32_t>(ff * 1000000000ull / 75)}; }
+};
 // (start, end) sample ranges of the tracks of one FILE entry: `(index.as_secs_f32() * SAMPLE_RATE as f32) as usize` for each
-// track's first INDEX; the last track runs to the end of the decoded file
+// track's first INDEX (src/cue.rs:214-215,232); the last track runs to the end of the decoded file.  index_seconds must hold
+// `Duration::as_secs_f32()` values (a float computed as mm * 60 + ss + ff / 75 is not the same number): use the CueIndex form
 inline std::vector<std::pair<uint64_t, uint64_t>> cue_track_bounds(const std::vector<float>& index_seconds, uint64_t n_samples) {
     std::vector<std::pair<uint64_t, uint64_t>> b;
     for (size_t i = 0; i < index_seconds.size(); i++) {
@@ -263,17 +277,29 @@ inline std::vector<std::pair<uint64_t, uint64_t>> cue_track_bounds(const std::ve
     }
     return b;
 }
+inline std::vector<std::pair<uint64_t, uint64_t>> cue_track_bounds(const std::vector<CueIndex>& index, uint64_t n_samples) {
+    std::vector<float> secs;
+    for (const CueIndex& ix : index) secs.push_back(ix.as_secs_f32());
+    return cue_track_bounds(secs, n_samples);
+}
 // The audio file of a CUE sheet as the decoder delivered it (`frames` frames of `channels` interleaved samples at `sample_rate`) ->
 // one result per track: the file is converted ONCE to mono 22 050 Hz on the device (FFmpegDecoder's conversion), the tracks are
 // (offset, length) slices of that device buffer.  Sheet parsing (the reference uses the rcue crate) stays with the host.
+// ctx: the context to run on; NULL = the library's first default context (borrowed: the one the entry points without a context
+// argument use -- no context is created or destroyed per CUE file).
 inline std::vector<BlissResult<Analysis>> analyze_cue_tracks(const void* pcm, int sample_format, uint32_t channels, uint64_t frames,
                                                              uint32_t sample_rate, const std::vector<float>& index_seconds,
-                                                             const AnalysisOptions& opt = {}) {
+                                                             const AnalysisOptions& opt = {}, blissgpu_ctx* ctx = nullptr) {
     struct Dev {  // device scratch of this call
         blissgpu_ctx* ctx = nullptr;
         void *raw = nullptr, *mono = nullptr, *rows = nullptr, *status = nullptr;
-        ~Dev() { blissgpu_free(raw); blissgpu_free(mono); blissgpu_free(rows); blissgpu_free(status); if (ctx) blissgpu_ctx_destroy(ctx); }
+        ~Dev() { blissgpu_free(raw); blissgpu_free(mono); blissgpu_free(rows); blissgpu_free(status); }
     } d;
+    if (channels == 0 || channels > 8) throw DecodingError("channels must be 1..8");
+    if (sample_format != BLISSGPU_SAMPLE_F32 && sample_format != BLISSGPU_SAMPLE_S16 && sample_format != BLISSGPU_SAMPLE_S32)
+        throw DecodingError("sample_format must be F32, S16 or S32");
+    d.ctx = ctx;
+    if (!d.ctx) check(blissgpu_default_ctx(0, &d.ctx));
     const size_t sample_bytes = sample_format == BLISSGPU_SAMPLE_S16 ? 2 : 4;
     const uint64_t n_mono = blissgpu_resampled_len(frames, sample_rate);
     const auto bounds = cue_track_bounds(index_seconds, n_mono);
@@ -285,7 +311,6 @@ inline std::vector<BlissResult<Analysis>> analyze_cue_tracks(const void* pcm, in
         off[i] = bounds[i].first;
         len[i] = bounds[i].second - bounds[i].first;
     }
-    check(blissgpu_ctx_create(0, &d.ctx));
     check(blissgpu_malloc(&d.raw, std::max<uint64_t>(1, frames * channels * sample_bytes)));
     check(blissgpu_malloc(&d.mono, std::max<uint64_t>(1, n_mono) * 4 + 256));
     check(blissgpu_malloc(&d.rows, std::max<size_t>(1, n * dft) * 4));
@@ -308,6 +333,13 @@ inline std::vector<BlissResult<Analysis>> analyze_cue_tracks(const void* pcm, in
         else res.emplace_back(AnalysisError("empty or too short song."));
     }
     return res;
+}
+inline std::vector<BlissResult<Analysis>> analyze_cue_tracks(const void* pcm, int sample_format, uint32_t channels, uint64_t frames,
+                                                             uint32_t sample_rate, const std::vector<CueIndex>& index,
+                                                             const AnalysisOptions& opt = {}, blissgpu_ctx* ctx = nullptr) {
+    std::vector<float> secs;
+    for (const CueIndex& ix : index) secs.push_back(ix.as_secs_f32());
+    return analyze_cue_tracks(pcm, sample_format, channels, frames, sample_rate, secs, opt, ctx);
 }
 
 // ---- Decoder trait (src/song/decoder.rs:34-333) ----

@@ -180,12 +180,17 @@ void default_ctx_forget_failures() {
         if (!seat.ctx) { seat.fails = 0; seat.permanent = false; seat.rc = BLISSGPU_OK; }
     }
 }
-// live contexts per HIP device in this process (the single-launch sort and the song_to_song chain spin on grid barriers:
-// they assume their workgroups are co-resident, which holds with margin for two contexts' worth of them on a device)
+// Live contexts per HIP device in this process.  The single-launch sort and the song_to_song chain spin on grid barriers: their
+// workgroups must all be resident at once.  One such kernel asks for at most one 256-thread workgroup per CU, so two contexts'
+// worth of them always fit beside each other; with more contexts alive on the device the sort falls back to one launch per
+// step, and the chain -- which has no multi-launch form -- runs one at a time per device (persistent_kernel_mutex: launch, wait
+// for it, release), so that two spinning grids can never hold each other's missing workgroups out of the CUs.
 namespace {
 std::mutex g_live_mu;
 std::vector<int> g_live_contexts;
+std::mutex g_persistent_mu[64];
 }
+std::mutex& persistent_kernel_mutex(int device) { return g_persistent_mu[(unsigned)device % 64u]; }
 void live_context_add(int device, int delta) {
     std::lock_guard<std::mutex> lk(g_live_mu);
     if (device < 0) return;
@@ -625,6 +630,9 @@ int blissgpu_song_to_song_device(blissgpu_ctx* c, const float* d_seeds, uint32_t
     rc = c->pl_sync.ensure(4);
     if (!rc) rc = c->pl_slots.ensure((size_t)2 * grid);
     if (rc) return rc;
+    // more than two contexts alive on this device: spinning grids of different contexts must not overlap (see live_contexts)
+    std::unique_lock<std::mutex> one_at_a_time;
+    if (live_contexts(c->device) > 2) one_at_a_time = std::unique_lock<std::mutex>(persistent_kernel_mutex(c->device));
     HIP_TRY(hipMemsetAsync(c->pl_sync.p, 0, 4 * sizeof(uint32_t), c->stream));
     {
         Prof p(c, K_SONG_TO_SONG);
@@ -632,6 +640,7 @@ int blissgpu_song_to_song_device(blissgpu_ctx* c, const float* d_seeds, uint32_t
                             c->stream);
     }
     HIP_TRY(hipGetLastError());
+    if (one_at_a_time.owns_lock()) HIP_TRY(hipStreamSynchronize(c->stream));  // the chain has left the CUs before the next one starts
     return nan_check(c, c->pl_sync.p + 1, "blissgpu_song_to_song_device");
 }
 

@@ -139,7 +139,14 @@ struct FeedSong {
 struct ResampleBank {
     SwrPlan plan;
     float* d_bank = nullptr;
+    size_t bytes = 0;
+    uint64_t last_use = 0;  // the context's swr_clock when it was last handed out (the cache evicts the least recently used)
 };
+// The banks a context keeps on the device: a few common rates cost kilobytes (44.1 kHz: 66 taps, 48 kHz: 147 x 72), an inexact
+// rate 1024 phases of up to ~1100 taps = 4.5 MB -- a long-running host fed odd rates must not grow without bound.
+#ifndef SWR_CACHE_BYTES
+#define SWR_CACHE_BYTES (64ull << 20)
+#endif
 
 // The device side of the pinned staging ring (staging_ring.hpp): page-locked slabs, one HIP stream per lane.
 constexpr int MAX_STAGE_LANES = 16;
@@ -241,7 +248,9 @@ struct blissgpu_ctx {
     std::vector<bg::SongDesc> last_songs;    // its descriptors (chunk order; SongDesc::row = the caller's song index)
     uint64_t last_chunks = 0;                // chunks of the last analyze call
     bg::HostFeed feed;
-    std::map<uint32_t, bg::ResampleBank> swr_banks;  // filter banks of the input rates seen so far (guarded by mu)
+    std::map<uint32_t, bg::ResampleBank> swr_banks;  // filter banks of recently seen input rates (guarded by mu; LRU, SWR_CACHE_BYTES)
+    size_t swr_bytes = 0;
+    uint64_t swr_clock = 0;
     // distances / playlist ordering scratch
     int n_cus = 0;
     bg::DevBuf<uint32_t> pl_sync, pl_keys;

@@ -2,7 +2,10 @@
 //
 // The reference's FFmpegDecoder sends every decoded frame through libswresample with its default options
 // (src/song/decoder/ffmpeg.rs:36-109: Context::get(in_format, in_layout, in_rate, F32 packed, MONO, 22050), run per
-// frame, flush).  The device kernel in kernels_pcm.hip reproduces that conversion bit for bit; this file computes what
+// frame, flush).  The device kernel in kernels_pcm.hip reproduces that conversion -- bit for bit at 44 100 Hz, the one-phase
+// 2 : 1 case every reference file needs and its Adler-32 tests pin; the many-phase paths (48 kHz: 147 phases, 441, the
+// 1024-phase inexact case, up-sampling with its flush reflection) are the same restatement of the published algorithm, held to
+// the oracle's independent one and to a sinusoid-reconstruction property but to no external number --; this file computes what
 // it needs on the host, in double like FFmpeg's build_filter():
 //   * taps  = ceil(32 / factor) rounded up to even, factor = min(22050 * 0.97 / in_rate, 1)  (filter_size 32, cutoff 0.97)
 //   * phase_count = 22050 / gcd(in_rate, 22050) when <= 1024 (exact_rational), else 1024 (phase_shift 10, nearest lower
@@ -13,7 +16,9 @@
 //     in_rate * phase_count / 22050
 //   * the stream is extended by `taps` samples mirrored about sample 0 and by (min(left, taps) + 1) / 2 samples
 //     mirrored behind the end; the output count follows from that (= ceil(frames * 22050 / in_rate) for every rate tried)
-// Pinned through the kernel by the reference's Adler-32 decoder tests (ffmpeg.rs:433-452, 471-476).
+// Pinned through the kernel by the reference's Adler-32 decoder tests (ffmpeg.rs:433-452, 471-476): 44 100 Hz only.
+// (swr_i0 below is a power series where FFmpeg's bessel() is a rational approximation: equal to the last f32 bit of every bank
+// entry at 44 100 Hz -- the hashes say so -- and unverified elsewhere for the same reason.)
 #pragma once
 #include <cmath>
 #include <cstdint>

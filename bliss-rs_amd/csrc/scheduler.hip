@@ -348,6 +348,7 @@ void scheduler_release(blissgpu_ctx* c) {
     for (auto& kv : c->swr_banks)
         if (kv.second.d_bank) (void)hipFree(kv.second.d_bank);
     c->swr_banks.clear();
+    c->swr_bytes = 0;
     for (hipStream_t& cs : f.copy_stream)
         if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); cs = nullptr; }
     f.h_rows.release();
@@ -386,14 +387,27 @@ int resample_bank(blissgpu_ctx* c, uint32_t rate, const ResampleBank** out, cons
             return fail(BLISSGPU_ERR_INVALID, who, "sample_rate must be 1 .. 768000 Hz");
         std::vector<float> bank;
         swr_make_filter(rb.plan, bank);
+        rb.bytes = bank.size() * sizeof(float);
+        // room in the cache: the least recently used banks go (hipFree waits for the device, so a kernel still reading one has
+        // finished); the bank being added always stays
+        while (!c->swr_banks.empty() && c->swr_bytes + rb.bytes > (size_t)SWR_CACHE_BYTES) {
+            auto lru = c->swr_banks.begin();
+            for (auto q = c->swr_banks.begin(); q != c->swr_banks.end(); ++q)
+                if (q->second.last_use < lru->second.last_use) lru = q;
+            if (lru->second.d_bank) (void)hipFree(lru->second.d_bank);
+            c->swr_bytes -= lru->second.bytes;
+            c->swr_banks.erase(lru);
+        }
         float* d = nullptr;
-        hipError_t e = hipMalloc((void**)&d, bank.size() * sizeof(float));
+        hipError_t e = hipMalloc((void**)&d, rb.bytes);
         if (e != hipSuccess) { (void)hipGetLastError(); return fail(BLISSGPU_ERR_OOM, "hipMalloc(resample bank)", hipGetErrorString(e)); }
-        e = hipMemcpy(d, bank.data(), bank.size() * sizeof(float), hipMemcpyHostToDevice);
+        e = hipMemcpy(d, bank.data(), rb.bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(d); return fail(BLISSGPU_ERR_HIP, "hipMemcpy(resample bank)", hipGetErrorString(e)); }
         rb.d_bank = d;
+        c->swr_bytes += rb.bytes;
         it = c->swr_banks.emplace(rate, rb).first;
     }
+    it->second.last_use = ++c->swr_clock;
     *out = &it->second;
     return BLISSGPU_OK;
 }
@@ -478,6 +492,18 @@ int analyze_host_songs(blissgpu_ctx* c, const FeedSong* in, uint32_t n_songs, ui
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     HostFeed& f = c->feed;
+    // the filter banks of this call's rates are built (a blocking allocation + upload each, once per context and rate) BEFORE the
+    // first transfer is queued, not in the middle of the pipeline
+    {
+        uint32_t last_rate = SWR_OUT_RATE;
+        for (uint32_t i = 0; i < n_songs; i++)
+            if (in[i].rate != SWR_OUT_RATE && in[i].rate != last_rate && in[i].frames) {
+                const ResampleBank* rb;
+                const int brc = resample_bank(c, in[i].rate, &rb, who);
+                if (brc) return brc;
+                last_rate = in[i].rate;
+            }
+    }
     if (!f.copy_stream[N_COPY_STREAMS - 1]) {
         for (hipStream_t& cs : f.copy_stream)
             if (!cs) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));

@@ -227,7 +227,8 @@ class Context:
     def pcm_decode(self, pcm, sample_rate: int, out=None):
         """On-device conversion of decoder output (1-D mono or [frames, channels]; int16 / int32 / float32) at `sample_rate`
         Hz to the mono 22 050 Hz f32 stream Song::analyze takes: libswresample's default resampler as FFmpegDecoder drives
-        it (src/song/decoder/ffmpeg.rs:36-109), bit for bit (Adler-32 pins of ffmpeg.rs:433-452, 471-476)."""
+        it (src/song/decoder/ffmpeg.rs:36-109) -- bit for bit at 44 100 Hz (Adler-32 pins of ffmpeg.rs:433-452, 471-476); other
+        rates run the same restatement, held to the oracle only."""
         torch = self.torch
         assert pcm.is_cuda and pcm.dim() in (1, 2) and pcm.dtype in (torch.int16, torch.int32, torch.float32)
         pcm = pcm.contiguous()

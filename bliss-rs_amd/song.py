@@ -192,7 +192,7 @@ def _results(out, status, version):
 def analyze_decoded_batch(sample_arrays: Sequence[np.ndarray], sample_rates, options: Optional[AnalysisOptions] = None):
     """Decoder output at ANY sample rate -> analysis: what FFmpegDecoder::decode + Song::analyze do together
     (src/song/decoder/ffmpeg.rs:36-109, src/song/decoder.rs:85-101), with libswresample's conversion to mono 22 050 Hz
-    done on the device, bit for bit.  sample_rates: one rate for all songs or one per song."""
+    done on the device (bit for bit at 44 100 Hz, the rate the reference pins).  sample_rates: one rate for all songs or one per song."""
     options = options or AnalysisOptions()
     version = FeaturesVersion(options.features_version)
     arrays = [_as_pcm(a) for a in sample_arrays]

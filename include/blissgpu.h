@@ -188,13 +188,15 @@ int blissgpu_analyze_batch_interleaved(const void *pcm, int sample_format, uint3
  * The reference's FFmpegDecoder hands every decoded frame to libswresample with its default options (Kaiser-windowed sinc,
  * filter_size 32, cutoff 0.97, exact rational phases) and asks for mono f32 at 22 050 Hz.  These entry points take what the
  * DECODER delivers -- `frames` frames of `channels` interleaved samples at `sample_rate` Hz -- and do that conversion ON THE
- * DEVICE, bit for bit: widening (s16 / s32), libswresample's resampler with the summation order of its AVX2 + FMA3 kernel,
+ * DEVICE -- bit for bit at 44 100 Hz, the only rate the reference pins --: widening (s16 / s32), libswresample's resampler with the summation order of its AVX2 + FMA3 kernel,
  * the stream mirrored at both ends, stereo = each channel resampled, then l * sqrt(1/2) + r * sqrt(1/2) (more channels: the
  * sequential mean first, as src/song/decoder/symphonia.rs:291-297, then the resampler).  sample_rate 22 050 is the pass-through
  * of blissgpu_analyze_interleaved.  Pinned by the reference's own Adler-32 decoder tests: 0xa0f8b8af
  * (data/s32_mono_44_1_kHz.flac), 0xbbcba1cf (s32_stereo_44_1_kHz.flac) -- ffmpeg.rs:433-445 -- and 0xd594429c (no_channel.wav,
  * :471-476); with it the three CUE tracks of data/testcue.flac give the 3 x 23 features src/cue.rs:270-415 asserts.
- * Rates other than 44 100 Hz run the same code but no reference test holds a number for them. */
+ * Rates other than 44 100 Hz (147 / 441 / 1024 phases, up-sampling) run the same restatement of libswresample's published
+ * algorithm; no reference test holds a number for them and no FFmpeg build was available to make one: they are held to the
+ * oracle's independent restatement bit for bit and to a sinusoid-reconstruction property, i.e. NOT externally pinned. */
 int blissgpu_analyze_decoded(const void *pcm, int sample_format, uint32_t channels, uint64_t frames, uint32_t sample_rate,
                              uint32_t features_version, float *out, int32_t *status);
 /* Bulk form: every song with its own buffer, format, channel count and rate (a library is a mix of 44.1 and 48 kHz, mono

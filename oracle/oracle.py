@@ -10,10 +10,13 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libbliss_oracle.so")
+# BLISS_ORACLE_SO: another build of the same source (the --coverage build of `make -C oracle coverage`)
+_SO = os.environ.get("BLISS_ORACLE_SO") or os.path.join(_HERE, "libbliss_oracle.so")
 
 
 def build(force=False):
+    if os.environ.get("BLISS_ORACLE_SO"):
+        return _SO
     src = os.path.join(_HERE, "bliss_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])

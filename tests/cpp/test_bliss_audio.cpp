@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
         std::memcpy(st.data(), raw.data(), st.size() * 2);
         std::vector<float> want(69);
         { std::ifstream g(argv[7]); for (auto& v : want) g >> v; }
-        const std::vector<float> idx = {0.0f, 11.0f + 5.0f / 75.0f, 16.0f + 69.0f / 75.0f};  // INDEX 01 0:00:00, 0:11:05, 0:16:69
+        const std::vector<CueIndex> idx = {CueIndex::from_msf(0, 0, 0), CueIndex::from_msf(0, 11, 5), CueIndex::from_msf(0, 16, 69)};  // INDEX 01 of data/testcue.cue
         auto tracks = analyze_cue_tracks(st.data(), BLISSGPU_SAMPLE_S16, 2, st.size() / 2, 44100, idx);
         CHECK(tracks.size() == 3);
         for (size_t t = 0; t < 3; t++) {
@@ -104,6 +104,11 @@ int main(int argc, char** argv) {
         }
         const auto b = cue_track_bounds(idx, 496272);
         CHECK(b[0].second == 244020 && b[1].first == 244020 && b[1].second == 373086 && b[2].second == 496272);
+        // Duration::as_secs_f32 is secs as f32 + nanos as f32 / 1e9, not the exact sum rounded once: 00:00:05 starts at sample
+        // 1469 (the single rounding says 1470), 00:00:11 at 3234 (3233) -- src/cue.rs:214-215
+        const auto o = cue_track_bounds(std::vector<CueIndex>{CueIndex::from_msf(0, 0, 5), CueIndex::from_msf(0, 0, 11), CueIndex::from_msf(0, 1, 14)}, 99999);
+        CHECK(o[0].first == 1469 && o[1].first == 3234 && o[2].first == 26166);
+        CHECK((uint64_t)((0.0f + 5.0f / 75.0f) * 22050.0f) == 1470);
     }
     // bulk path: a missing file is reported, not fatal (src/song/decoder.rs:313-325)
     auto res = dec.analyze_paths({argv[1], "/nonexistent.raw"});

@@ -540,7 +540,7 @@ def test_decoder_trait_bulk_path(bliss, oracle, tmp_path, golden_pcm):
     assert song.path == str(good) and song.features_version == bliss.FeaturesVersion.LATEST
     assert abs(song.duration - len(golden_pcm) / 22050) < 1e-6
     ref = oracle.song_analyze(golden_pcm)
-    assert np.abs(song.analysis.as_arr1() - ref).max() < 1e-4
+    assert np.abs(song.analysis.as_arr1() - ref).max() <= FEATURE_TOL   # the reference's recording: all 23 within its own tolerance
     assert song.analysis[bliss.AnalysisIndex.Zcr] == pytest.approx(-0.849141, abs=1e-6)
     res = dict(D.analyze_paths([str(good), str(short), missing]))
     assert isinstance(res[str(good)], bliss.Song) and res[str(good)].analysis == song.analysis

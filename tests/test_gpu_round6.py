@@ -225,3 +225,72 @@ def test_threads_calling_the_single_song_entry_point_with_heap_buffers(bliss, dc
     _ffi.check(L.blissgpu_analyze_batch(flat.data_ptr(), offs.ctypes.data_as(C.POINTER(C.c_uint64)), lens.ctypes.data_as(C.POINTER(C.c_uint64)),
                                         T * per, 2, ref.ctypes.data, st.ctypes.data_as(C.POINTER(C.c_int32))))
     assert np.array_equal(rows.view(np.uint32), ref.view(np.uint32))
+
+
+def test_resample_bank_cache_is_bounded_and_evicted_banks_come_back(bliss, oracle):
+    """A context keeps the device filter bank of every input rate it has seen -- up to 64 MiB (round 5 advice: a long-running
+    host fed odd rates grew without bound).  Thirty inexact rates (1024 phases x ~100 - 1100 taps, up to 4.5 MB each) push the
+    first bank out; asking for the first rate again rebuilds it and gives the same samples bit for bit, and every rate still
+    equals the oracle."""
+    import torch
+
+    ctx = bliss.Context(0)
+    try:
+        rng = np.random.default_rng(5)
+        x = rng.integers(-20000, 20000, 40000, dtype=np.int16)
+        d_x = torch.from_numpy(x).cuda()
+        first_rate = 700001
+        first = ctx.pcm_decode(d_x, first_rate).cpu().numpy()
+        total = 0
+        for k in range(30):
+            rate = 500009 + 9973 * k   # no small common factor with 22 050: 1024 phases, 700 - 1100 taps
+            got = ctx.pcm_decode(d_x, rate)
+            ctx.synchronize()
+            taps, phases = oracle.swr_filter(rate)[1].taps, oracle.swr_filter(rate)[1].phase_count
+            total += taps * (phases + 1) * 4
+            if k % 10 == 0:
+                assert np.array_equal(got.cpu().numpy().view(np.uint32), oracle.decode_to_mono(x, rate).view(np.uint32)), rate
+        assert total > 80 << 20, total   # more than the cache holds: the first bank has been evicted
+        again = ctx.pcm_decode(d_x, first_rate).cpu().numpy()
+        assert np.array_equal(first.view(np.uint32), again.view(np.uint32))
+        assert np.array_equal(first.view(np.uint32), oracle.decode_to_mono(x, first_rate).view(np.uint32))
+    finally:
+        ctx.close()
+
+
+def test_song_to_song_chains_of_many_contexts_do_not_wait_for_each_other(bliss, oracle):
+    """The greedy chain is one persistent launch that spins on grid barriers; with more than two contexts alive on a device the
+    chains run one at a time (round 5 advice: only the sort was gated).  Five contexts, five threads, each its own pool: every
+    chain ends and equals the oracle's."""
+    import torch
+
+    n_ctx = 5
+    ctxs = [bliss.Context(0) for _ in range(n_ctx)]
+    try:
+        rng = np.random.default_rng(9)
+        pools = [rng.random((3000 + 500 * k, 23), np.float32) for k in range(n_ctx)]
+        got, errs = [None] * n_ctx, []
+
+        def work(k):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    c = ctxs[k]
+                    c.bind_current_stream()
+                    p = torch.from_numpy(pools[k]).cuda()
+                    for _ in range(3):
+                        order = c.song_to_song(p[:1], p, "euclidean")
+                    c.synchronize()
+                    got[k] = order.cpu().numpy()
+            except Exception as e:  # noqa: BLE001
+                errs.append((k, repr(e)))
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(n_ctx)]
+        [t.start() for t in th]
+        [t.join(timeout=120) for t in th]
+        assert not any(t.is_alive() for t in th), "a chain is still spinning"
+        assert not errs, errs
+        for k in range(n_ctx):
+            assert np.array_equal(got[k], oracle.song_to_song(pools[k][:1], pools[k], "euclidean")), k
+    finally:
+        for c in ctxs:
+            c.close()

@@ -209,6 +209,56 @@ def test_cpp_host_mirror_compiles(tmp_path, bliss):
         assert out.returncode != 0 and "no usable HIP device" in out.stderr
 
 
+def test_cue_track_bounds_follow_duration_as_secs_f32(tmp_path, bliss):
+    """BlissCueFile::get_songs turns an INDEX into a sample with `(index.as_secs_f32() * SAMPLE_RATE as f32) as usize`
+    (src/cue.rs:214-215, 232), and `Duration::as_secs_f32` is `secs as f32 + nanos as f32 / 1e9` -- two roundings and a rounded
+    quotient.  Rounding the exact mm * 60 + ss + ff / 75 once instead moves 72 of the 360 000 track starts of an 80-minute disc
+    by one sample.  The Python helper, the test mirror in conftest and the C++ mirror all follow the Duration formula; the twelve
+    first diverging indices are pinned by value, and the three INDEX lines of the reference's own sheet (data/testcue.cue:
+    244 020, 373 086) are not among them."""
+    from conftest import cue_bounds
+
+    f32 = np.float32
+    diverging = []
+    for mm in range(80):
+        for ss in range(60):
+            for ff in range(75):
+                want = int((f32(mm * 60 + ss) + f32(ff * 1_000_000_000 // 75) / f32(1e9)) * f32(22050))
+                once = int(f32(mm * 60 + ss + ff / 75.0) * f32(22050))
+                got = bliss.cue.cue_track_bounds([(mm, ss, ff)], 10**9)[0][0] if (want != once or ff == 0 and ss % 20 == 0) else want
+                assert got == want, (mm, ss, ff)
+                if want != once:
+                    diverging.append((mm, ss, ff, want))
+    assert len(diverging) == 72
+    assert diverging[:12] == [(0, 0, 5, 1469), (0, 0, 11, 3234), (0, 0, 22, 6468), (0, 0, 23, 6761), (0, 0, 44, 12936), (0, 0, 46, 13523),
+                              (0, 0, 55, 16169), (0, 1, 5, 23519), (0, 1, 14, 26166), (0, 1, 24, 29105), (0, 1, 46, 35573), (0, 1, 64, 40865)]
+    msf = [d[:3] for d in diverging]
+    assert [b[0] for b in cue_bounds(msf, 10**9)] == [d[3] for d in diverging]
+    assert [b[0] for b in bliss.cue.cue_track_bounds([bliss.cue.cue_index_duration(*m) for m in msf], 10**9)] == [d[3] for d in diverging]
+    assert bliss.cue.cue_track_bounds([(0, 0, 0), (0, 11, 5), (0, 16, 69)], 496272) == [(0, 244020), (244020, 373086), (373086, 496272)]
+    # the C++ mirror (bliss::CueIndex), device-free
+    src = tmp_path / "cue_idx.cpp"
+    src.write_text("""
+#include <cstdio>
+#include "%s/bliss-rs_amd/csrc/bliss_audio.hpp"
+int main() {
+    for (unsigned mm = 0; mm < 80; mm++) for (unsigned ss = 0; ss < 60; ss++) for (unsigned ff = 0; ff < 75; ff++) {
+        const auto b = bliss::cue_track_bounds(std::vector<bliss::CueIndex>{bliss::CueIndex::from_msf(mm, ss, ff)}, 1000000000ull);
+        std::printf("%%llu\\n", (unsigned long long)b[0].first);
+    }
+    return 0;
+}
+""" % ROOT)
+    exe = tmp_path / "cue_idx"
+    libdir = os.path.join(ROOT, "bliss-rs_amd")
+    for flags in (["-O0"], ["-O2", "-march=native", "-ffp-contract=fast"]):   # (the quotient is rounded before the add whatever the flags)
+        subprocess.check_call(["g++", "-std=c++17"] + flags + [str(src), "-o", str(exe), f"-L{libdir}", "-lblissgpu", f"-Wl,-rpath,{libdir}"])
+        got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+        want = [int((f32(mm * 60 + ss) + f32(ff * 1_000_000_000 // 75) / f32(1e9)) * f32(22050))
+                for mm in range(80) for ss in range(60) for ff in range(75)]
+        assert got == want, flags
+
+
 # ---------------------------------------------------------------------------------------------
 # the sharding plan of the C ABI (device-free) against the torch.distributed form, at the sizes
 # configs[2] / configs[4] shard at
