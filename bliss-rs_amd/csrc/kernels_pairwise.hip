@@ -12,9 +12,12 @@
 // With M = I (or any diagonal M) the vector-matrix product degenerates exactly to an element-wise
 // product, which is the fast path.
 //
-// HBM-write bound: 4 bytes per pair out, 4*d*(n+m) bytes in.  A workgroup owns a 128-row x 256-column
-// tile; each lane keeps 4 column vectors in registers, rows come from LDS as broadcasts, and every
-// wave-store is 64 lanes x 16 B = 1 KiB of one output row.
+// 4 bytes per pair out, 4*d*(n+m) bytes in.  A workgroup owns 256 columns -- each lane keeps 4 column vectors in
+// registers -- and walks PW_RT tiles of 128 rows down them (round 6: the columns are 92 strided loads per lane and used
+// to be reloaded for every tile); rows come from LDS as broadcasts, and every wave-store is 64 lanes x 16 B = 1 KiB of
+// one output row.  Bound by the vector ALU, not by its stores (profiles/r06_pairwise_ablation.txt: the self-distance
+// kernel takes 9.7 of its 10.7 ms with every store removed): 136 packed operations + four correctly rounded square
+// roots (a quarter-rate instruction each) per four outputs is what the reference's summation order costs.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -25,6 +28,9 @@
 namespace bg {
 
 constexpr int PW_ROWS = 128, PW_COLS = 256, PW_CPT = 4;  // tile rows, tile cols, cols per thread
+#ifndef PW_RT
+#define PW_RT 8   // 128-row tiles a workgroup walks with its 256 columns in registers (even: the self-distance kernel works in 256 x 256 blocks)
+#endif
 enum { METRIC_EUCLIDEAN = 0, METRIC_COSINE = 1, METRIC_MAHALANOBIS = 2 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -124,7 +130,7 @@ __device__ __forceinline__ float unrolled_dot(FX xs, FY ys) {
 // blocks on or above the diagonal are computed; an off-diagonal block is also written transposed, 32 rows at a time
 // through an LDS tile so that the transposed stores are 128-byte runs.
 template <int D, int METRIC, bool DIAG, bool SYM = false>
-__global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restrict__ A, uint64_t n,
+__global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pairwise_kernel(const float* __restrict__ A, uint64_t n,
                                                        const float* __restrict__ B, uint64_t m,
                                                        const float* __restrict__ M, float* __restrict__ out,
                                                        uint64_t ld_out) {
@@ -132,7 +138,10 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float sa[PW_ROWS][DP];
     __shared__ float sna[PW_ROWS];
     __shared__ float sm[(METRIC == METRIC_MAHALANOBIS) ? D * D : 1];
-    constexpr int T_ROWS = 32;  // rows staged per transposed write
+#ifndef PW_T_ROWS
+#define PW_T_ROWS 32
+#endif
+    constexpr int T_ROWS = PW_T_ROWS;  // rows staged per transposed write
     constexpr int T_PITCH = T_ROWS + 1;
     // (odd pitch: the 8 lanes that assemble one 128-byte run read 8 different banks.  The STORES into this tile are four
     // lanes to a bank -- 38 % of the kernel's LDS cycles are conflicts -- but the layout without any, word c * 2113 + 33 l +
@@ -141,23 +150,19 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
     __shared__ float st[SYM ? PW_COLS : 1][SYM ? T_PITCH : 1];  // staged TRANSPOSED: st[column][row]
     auto st_at = [&](int col, int row) -> float& { return st[col][row]; };
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-    const uint32_t bi = blockIdx.y / (PW_COLS / PW_ROWS), bj = blockIdx.x;  // 256 x 256 block coordinates
-    if (SYM && bj < bi) return;                                              // mirrored from the block (bj, bi)
-    const bool do_t = SYM && bj > bi;
-    const uint64_t i0 = (uint64_t)blockIdx.y * PW_ROWS;
+    const uint32_t bj = blockIdx.x;  // 256-column block
+    bool do_t = false;               // this tile's block lies above the diagonal: it is also written transposed
+    // A workgroup walks RT row tiles of 128 rows with ITS columns kept in registers (round 6): the columns are 92 strided 4-byte
+    // loads per lane, the same in all four wavefronts -- as much traffic through the CU's load path as 40 rows of arithmetic --
+    // and were reloaded for every 128 rows.
+    constexpr int RT = PW_RT;
+    static_assert(RT % (PW_COLS / PW_ROWS) == 0, "a workgroup of the self-distance kernel walks whole 256 x 256 blocks");
+    uint64_t i0 = (uint64_t)blockIdx.y * PW_ROWS * RT;
+    if (SYM && i0 / PW_COLS > bj) return;  // every block of this workgroup lies below the diagonal: mirrored from above
     const uint64_t j0 = (uint64_t)blockIdx.x * PW_COLS + (uint64_t)lane * PW_CPT;
-
-    // stage the row tile and, for cosine, the row norms
-    const uint64_t rows_here = (n - i0 < (uint64_t)PW_ROWS) ? n - i0 : (uint64_t)PW_ROWS;
-    for (int e = tid; e < (int)rows_here * D; e += 256) sa[e / D][e % D] = A[i0 * D + e];
-    if (METRIC == METRIC_MAHALANOBIS)
+    uint64_t rows_here = 0;
+    if (METRIC == METRIC_MAHALANOBIS) {
         for (int e = tid; e < D * D; e += 256) sm[e] = M[e];
-    __syncthreads();
-    if (METRIC == METRIC_COSINE) {
-        if (tid < (int)rows_here) {
-            const float* a = sa[tid];
-            sna[tid] = sqrtf(unrolled_dot<D>([&](int k) { return a[k]; }, [&](int k) { return a[k]; }));
-        }
         __syncthreads();
     }
 
@@ -183,84 +188,157 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
     for (int k = 0; k < D; k++) wdiag[k] = DIAG ? sm[(k * D + k) % (METRIC == METRIC_MAHALANOBIS ? D * D : 1)] : 0.0f;
 
     const bool vec_ok = ((ld_out & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && (j0 + 3 < m);
-    for (int R0 = 0; R0 < (int)rows_here; R0 += T_ROWS) {
-    for (int r = R0 + wave; r < (int)rows_here && r < R0 + T_ROWS; r += 4) {
-        f2 ap[DP / 2];  // the row, two features per register pair
+    // ---- one row of the tile against the lane's four columns, in pieces so that the loop below can put the tail of one row (the
+    // correctly rounded square root: a quarter-rate instruction and two dependent steps behind it) beside the packed arithmetic
+    // of the next.  Measured: 0.7 % (profiles/r06_pairwise_two_rows_ab.txt) -- with three wavefronts per SIMD the latencies at
+    // the head and the tail of a row were already covered; kept for the A != B Euclidean form, where it costs no registers.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+#ifndef PW_PIPELINED
+#define PW_PIPELINED 1
+#endif
+    constexpr bool PIPELINED = PW_PIPELINED && METRIC == METRIC_EUCLIDEAN && !SYM;  // (the other forms spill at three waves per SIMD)
+    auto load_row = [&](f2 (&ap)[DP / 2], int r) __attribute__((always_inline)) {
 #pragma unroll
         for (int k4 = 0; k4 < DP / 4; k4++) {  // same address in every lane: LDS broadcast
             const float4 q = *reinterpret_cast<const float4*>(&sa[r][4 * k4]);
             ap[2 * k4].x = q.x; ap[2 * k4].y = q.y; ap[2 * k4 + 1].x = q.z; ap[2 * k4 + 1].y = q.w;
         }
-        float res[PW_CPT];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            // term k of the unrolled_dot for the two columns of pair h
-            auto term = [&](auto kc) -> f2 {
-                constexpr int k = decltype(kc)::value;
-                constexpr bool HI = (k & 1) != 0;
-                if (METRIC == METRIC_COSINE) return bmul<HI>(ap[k / 2], bp[h][k]);
-                const f2 v = bsub<HI>(ap[k / 2], bp[h][k]);
-                if (METRIC == METRIC_EUCLIDEAN) return v * v;
-                if (DIAG) return (v * splat(wdiag[k])) * v;
-                return v;  // unused (general M handled below)
-            };
-            f2 q;
-            if (METRIC == METRIC_MAHALANOBIS && !DIAG) {
-                f2 v[D], t[D];
-                static_for<D>([&](auto kc) { v[decltype(kc)::value] = term(kc); });
+    };
+    // the reference's sum for the two columns of pair h (before the square root / the cosine's division)
+    auto row_sum = [&](const f2 (&ap)[DP / 2], auto hc) __attribute__((always_inline)) -> f2 {
+        constexpr int h = decltype(hc)::value;
+        // term k of the unrolled_dot for the two columns of pair h
+        auto term = [&](auto kc) __attribute__((always_inline)) -> f2 {
+            constexpr int k = decltype(kc)::value;
+            constexpr bool HI = (k & 1) != 0;
+            if (METRIC == METRIC_COSINE) return bmul<HI>(ap[k / 2], bp[h][k]);
+            const f2 v = bsub<HI>(ap[k / 2], bp[h][k]);
+            if (METRIC == METRIC_EUCLIDEAN) return v * v;
+            if (DIAG) return (v * splat(wdiag[k])) * v;
+            return v;  // (general M: the difference itself)
+        };
+        if (METRIC == METRIC_MAHALANOBIS && !DIAG) {
+            f2 v[D], t[D];
+            static_for<D>([&](auto kc) { v[decltype(kc)::value] = term(kc); });
 #pragma unroll 1
-                for (int jj = 0; jj < D; jj++) {
-                    f2 acc = splat(0.0f);
+            for (int jj = 0; jj < D; jj++) {
+                f2 acc = splat(0.0f);
 #pragma unroll
-                    for (int ii = 0; ii < D; ii++) acc = acc + v[ii] * splat(sm[ii * D + jj]);
-                    t[jj] = acc;
-                }
-                const f2 sq = unrolled_dot2<D>([&](int k) { return t[k]; }, [&](int k) { return v[k]; });
-                q = sqrt_rn2(sq);
-            } else {
-                f2 p[8];
-                constexpr int BODY = (D / 8) * 8;
-                f2 sum;
-                if (METRIC == METRIC_EUCLIDEAN && BODY >= 8) {
-                    // every term is a square (>= +0), so the reference's `0.0 + term` and `0.0 + (p0 + p4)` are exact
-                    // identities: start the eight partial sums at their first term (10 of 78 packed instructions less)
-                    static_for<8>([&](auto kc) { p[decltype(kc)::value] = term(kc); });
-                    static_for<BODY - 8>([&](auto kc) { constexpr int k = 8 + decltype(kc)::value; p[k & 7] = p[k & 7] + term(std::integral_constant<int, k>{}); });
-                    sum = p[0] + p[4];
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 8; u++) p[u] = splat(0.0f);
-                    static_for<BODY>([&](auto kc) { constexpr int k = decltype(kc)::value; p[k & 7] = p[k & 7] + term(kc); });
-                    sum = splat(0.0f);
-                    sum = sum + (p[0] + p[4]);
-                }
-                sum = sum + (p[1] + p[5]);
-                sum = sum + (p[2] + p[6]);
-                sum = sum + (p[3] + p[7]);
-                static_for<D - BODY>([&](auto kc) { sum = sum + term(std::integral_constant<int, BODY + decltype(kc)::value>{}); });
-                if (METRIC == METRIC_COSINE) {
-                    q = splat(1.0f) - sum / (splat(sna[r]) * nb[h]);
-                } else {
-                    q = sqrt_rn2(sum);
-                }
+                for (int ii = 0; ii < D; ii++) acc = acc + v[ii] * splat(sm[ii * D + jj]);
+                t[jj] = acc;
             }
-            res[2 * h] = q.x;
-            res[2 * h + 1] = q.y;
+            return unrolled_dot2<D>([&](int k) { return t[k]; }, [&](int k) { return v[k]; });
         }
+        f2 p[8];
+        constexpr int BODY = (D / 8) * 8;
+        f2 sum;
+        if (METRIC == METRIC_EUCLIDEAN && BODY >= 8) {
+            // every term is a square (>= +0), so the reference's `0.0 + term` and `0.0 + (p0 + p4)` are exact
+            // identities: start the eight partial sums at their first term (10 of 78 packed instructions less)
+            static_for<8>([&](auto kc) { p[decltype(kc)::value] = term(kc); });
+            static_for<BODY - 8>([&](auto kc) { constexpr int k = 8 + decltype(kc)::value; p[k & 7] = p[k & 7] + term(std::integral_constant<int, k>{}); });
+            sum = p[0] + p[4];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; u++) p[u] = splat(0.0f);
+            static_for<BODY>([&](auto kc) { constexpr int k = decltype(kc)::value; p[k & 7] = p[k & 7] + term(kc); });
+            sum = splat(0.0f);
+            sum = sum + (p[0] + p[4]);
+        }
+        sum = sum + (p[1] + p[5]);
+        sum = sum + (p[2] + p[6]);
+        sum = sum + (p[3] + p[7]);
+        static_for<D - BODY>([&](auto kc) { sum = sum + term(std::integral_constant<int, BODY + decltype(kc)::value>{}); });
+        return sum;
+    };
+    // sum -> distance, the branch-free part (exact unless one of the four sums is a tiny positive number: fix_row)
+    auto finish_fast = [&](f2 sum, int h, int r) __attribute__((always_inline)) -> f2 {
+        if (METRIC == METRIC_COSINE) return splat(1.0f) - sum / (splat(sna[r]) * nb[h]);
+        f2 q;
+        q.x = sqrt_rn_fast(sum.x);
+        q.y = sqrt_rn_fast(sum.y);
+        return q;
+    };
+    auto is_tiny = [&](f2 a, f2 b) __attribute__((always_inline)) -> bool {  // v_sqrt_f32 does not take denormal inputs: sums below 2^-96 (and not 0) go the long way
+        if (METRIC == METRIC_COSINE) return false;
+        // x in (0, 2^-96)  <=>  bits(x) - 1 < bits(2^-96) - 1 as unsigned (0 wraps to the top, inf / NaN are large)
+        const uint32_t lo = min(min(__float_as_uint(a.x) - 1u, __float_as_uint(a.y) - 1u), min(__float_as_uint(b.x) - 1u, __float_as_uint(b.y) - 1u));
+        return lo < 0x0F800000u - 1u;
+    };
+    auto emit_row = [&](int r, int R0, f2 q0, f2 q1) __attribute__((always_inline)) {
         float* orow = out + (i0 + r) * ld_out + j0;
+#ifdef PW_ABL_NO_DSTORE
+        if (q0.x == 12345.678f)
+#endif
         if (vec_ok) {
-            typedef float f4 __attribute__((ext_vector_type(4)));
             f4 q4;
-            q4.x = res[0]; q4.y = res[1]; q4.z = res[2]; q4.w = res[3];
+            q4.x = q0.x; q4.y = q0.y; q4.z = q1.x; q4.w = q1.y;
             __builtin_nontemporal_store(q4, reinterpret_cast<f4*>(__builtin_assume_aligned(orow, 16)));  // written once, never re-read here
         } else {
+            const float res[PW_CPT] = {q0.x, q0.y, q1.x, q1.y};
 #pragma unroll
             for (int c = 0; c < PW_CPT; c++)
                 if (j0 + c < m) orow[c] = res[c];
         }
         if (do_t) {
-#pragma unroll
-            for (int c = 0; c < PW_CPT; c++) st_at(PW_CPT * lane + c, r - R0) = res[c];
+            st_at(PW_CPT * lane + 0, r - R0) = q0.x;
+            st_at(PW_CPT * lane + 1, r - R0) = q0.y;
+            st_at(PW_CPT * lane + 2, r - R0) = q1.x;
+            st_at(PW_CPT * lane + 3, r - R0) = q1.y;
+        }
+    };
+    for (int t = 0; t < RT && i0 < n; t++, i0 += PW_ROWS) {
+    if (SYM) {
+        const uint32_t bi = (uint32_t)(i0 / PW_COLS);  // block row of this tile
+        if (bi > bj) break;                            // mirrored from the block (bj, bi)
+#ifndef PW_ABL_NO_T   // (ablation builds, tests/tools/variant_obj.sh: what each phase of the self-distance kernel costs)
+        do_t = bj > bi;
+#endif
+    }
+    // stage the row tile and, for cosine, the row norms
+    if (t) __syncthreads();  // every wavefront has finished with the previous tile's rows
+    rows_here = (n - i0 < (uint64_t)PW_ROWS) ? n - i0 : (uint64_t)PW_ROWS;
+    for (int e = tid; e < (int)rows_here * D; e += 256) sa[e / D][e % D] = A[i0 * D + e];
+    __syncthreads();
+    if (METRIC == METRIC_COSINE) {
+        if (tid < (int)rows_here) {
+            const float* a = sa[tid];
+            sna[tid] = sqrtf(unrolled_dot<D>([&](int k) { return a[k]; }, [&](int k) { return a[k]; }));
+        }
+        __syncthreads();
+    }
+    for (int R0 = 0; R0 < (int)rows_here; R0 += T_ROWS) {
+    {
+        const int r_end = ((int)rows_here < R0 + T_ROWS) ? (int)rows_here : R0 + T_ROWS;
+        int r = R0 + wave;
+        if (PIPELINED) {
+            // two rows per trip, in ONE basic block: the first row's square roots are independent of the second row's 136
+            // packed operations (and its LDS reads of the first row's last differences), so the scheduler overlaps them
+#pragma unroll 1
+            for (; r + 4 < r_end; r += 8) {
+                f2 ap[DP / 2];  // the row, two features per register pair
+                load_row(ap, r);
+                const f2 sa0 = row_sum(ap, std::integral_constant<int, 0>{}), sa1 = row_sum(ap, std::integral_constant<int, 1>{});
+                load_row(ap, r + 4);
+                f2 qa0 = finish_fast(sa0, 0, r), qa1 = finish_fast(sa1, 1, r);
+                const f2 sb0 = row_sum(ap, std::integral_constant<int, 0>{}), sb1 = row_sum(ap, std::integral_constant<int, 1>{});
+                f2 qb0 = finish_fast(sb0, 0, r + 4), qb1 = finish_fast(sb1, 1, r + 4);
+                const bool tiny = is_tiny(sa0, sa1) || is_tiny(sb0, sb1);
+                if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {  // wave-uniform, next to never
+                    qa0.x = sqrtf(sa0.x); qa0.y = sqrtf(sa0.y); qa1.x = sqrtf(sa1.x); qa1.y = sqrtf(sa1.y);
+                    qb0.x = sqrtf(sb0.x); qb0.y = sqrtf(sb0.y); qb1.x = sqrtf(sb1.x); qb1.y = sqrtf(sb1.y);
+                }
+                emit_row(r, R0, qa0, qa1);
+                emit_row(r + 4, R0, qb0, qb1);
+            }
+        }
+#pragma unroll 1
+        for (; r < r_end; r += 4) {   // (the odd row of a ragged tile; every row of the general-M form)
+            f2 ap[DP / 2];
+            load_row(ap, r);
+            const f2 s0 = row_sum(ap, std::integral_constant<int, 0>{}), s1 = row_sum(ap, std::integral_constant<int, 1>{});
+            if (METRIC == METRIC_COSINE) emit_row(r, R0, finish_fast(s0, 0, r), finish_fast(s1, 1, r));
+            else emit_row(r, R0, sqrt_rn2(s0), sqrt_rn2(s1));
         }
     }
     if (do_t) {  // workgroup-uniform
@@ -269,13 +347,17 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
         // assembled by 8 consecutive lanes (16 bytes each) so that every store instruction writes whole lines
         const int nvalid = ((int)rows_here - R0 < T_ROWS) ? (int)rows_here - R0 : T_ROWS;
         const bool fast = nvalid == T_ROWS && ((ld_out & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-        const int chunk = tid & 7;
-#pragma unroll
-        for (int p = 0; p < PW_COLS / 32; p++) {
-            const int j = 32 * p + (tid >> 3);
+        constexpr int LPR = T_ROWS / 4, JPP = 256 / LPR;  // lanes per run of T_ROWS floats, runs per pass of the workgroup
+        const int chunk = tid % LPR;
+#pragma unroll 1   // (unrolled, the eight row pointers are hoisted out of the tile loop and held across the arithmetic: 16 registers)
+        for (int p = 0; p < PW_COLS / JPP; p++) {
+            const int j = JPP * p + tid / LPR;
             const uint64_t jrow = (uint64_t)bj * PW_COLS + (uint64_t)j;
             if (jrow >= m) continue;
             float* dst = out + jrow * ld_out + i0 + (uint64_t)R0 + 4 * chunk;
+#ifdef PW_ABL_NO_TSTORE
+            if (st_at(j, 4 * chunk) != 12345.678f) continue;
+#endif
             if (fast) {
                 typedef float f4 __attribute__((ext_vector_type(4)));
                 f4 v4;
@@ -287,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void pairwise_kernel(const float* __restric
             }
         }
         __syncthreads();
+    }
     }
     }
 }
@@ -337,7 +420,7 @@ __global__ __launch_bounds__(256) void pairwise_generic_kernel(const float* __re
 template <int D>
 static void launch_d(const float* A, uint64_t n, const float* B, uint64_t m, int metric, const float* M, int diag,
                      float* out, uint64_t ld, hipStream_t st) {
-    const dim3 grid((uint32_t)((m + PW_COLS - 1) / PW_COLS), (uint32_t)((n + PW_ROWS - 1) / PW_ROWS));
+    dim3 grid((uint32_t)((m + PW_COLS - 1) / PW_COLS), (uint32_t)((n + (uint64_t)PW_ROWS * PW_RT - 1) / ((uint64_t)PW_ROWS * PW_RT)));
     if (A == B && n == m) {  // self-distance matrix: upper block triangle + mirrored stores
         if (metric == METRIC_EUCLIDEAN)
             hipLaunchKernelGGL((pairwise_kernel<D, METRIC_EUCLIDEAN, false, true>), grid, dim3(256), 0, st, A, n, B, m, M, out, ld);
