@@ -506,6 +506,21 @@ def main():
                 "frac": round(flops_step / (elapsed / args.steps) / FP32_PEAK, 5),
                 "note": "whole step on this GPU; 1.4e9 FP32-equivalent flop per 3-min song (real-input FFT counts), scaled by samples"}
 
+        # what BINDS the dominant kernel: its VALU-busy fraction from the committed counter pass (tests/tools/valu_busy.sh ->
+        # profiles/valu_busy.json; like the traffic figure it cannot be read from inside the process it profiles and is refused
+        # when the kernel sources have changed since it was measured)
+        valu = {"bound": "valu-issue", "kernel": dom, "frac": None, "unit": "fraction of SIMD cycles with a VALU instruction in flight"}
+        try:
+            vb = json.load(open(os.path.join(ROOT, "profiles", "valu_busy.json")))
+            if vb.get("kernel_sources_sha256") != kernel_sources_sha():
+                valu["source"] = "profiles/valu_busy.json REFUSED: measured on other kernel sources (re-run tests/tools/valu_busy.sh)"
+            else:
+                valu["frac"] = vb["kernels"][dom]["valu_busy"]
+                valu["all"] = {k: v["valu_busy"] for k, v in vb["kernels"].items()}
+                valu["source"] = "profiles/valu_busy.json: " + vb.get("note", "")
+        except Exception as e:  # noqa: BLE001
+            valu["source"] = f"profiles/valu_busy.json: {type(e).__name__}"
+
         result = {
             "metric": "songs/sec (3-min 22 050 Hz f32) at 1/2/4/8 GPU; HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "songs/sec", "n_gpus": world, "steps": args.steps,
@@ -517,7 +532,7 @@ def main():
                        "parallelism": f"songs sharded x{world}, all-gather of feature rows" if world > 1 else "single GPU"},
             "samples_per_sec": round(job_samples * args.steps / elapsed, 1),
             "three_minute_song_equivalents_per_sec": round(job_samples * args.steps / elapsed / SONG_SAMPLES, 2),
-            "roofline": roofline, "roofline_fp32": fp32,
+            "roofline": roofline, "roofline_fp32": fp32, "roofline_valu": valu,
         }
         result.update(notes)
         if args.share_device:

@@ -294,3 +294,25 @@ def test_song_to_song_chains_of_many_contexts_do_not_wait_for_each_other(bliss, 
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_the_three_big_kernels_are_not_slower_than_recorded():
+    """A regression guard on the per-stage table (what benches/analysis_pipeline.rs:8-126 prints for the reference's stages):
+    stft8192 / fft512 / chroma make 34 of the step's 37 ms; each, timed alone (serial mode, best of 5 steps of 1024 three-minute
+    songs), must stay within 6 % of the minimum recorded in profiles/kernel_times_serial.json (tests/tools/kernel_times.py; boxes
+    of the pool differ by about 3 %)."""
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = json.load(open(os.path.join(root, "profiles", "kernel_times_serial.json")))
+    sys.path.insert(0, os.path.join(root, "tests", "tools"))
+    from kernel_times import BIG, measure
+
+    assert ref["songs"] == 1024
+    got = measure(1024, 5)
+    report = {k: (got[k]["min_ms"], ref["kernels"][k]["min_ms"]) for k in BIG}
+    print("kernel: measured min ms, recorded min ms:", report)
+    for k, (now, then) in report.items():
+        assert now <= 1.06 * then, (k, now, then)
