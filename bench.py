@@ -44,7 +44,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=("batch", "mixed", "library"), default="batch")
+    ap.add_argument("--config", choices=("batch", "mixed", "library", "musical"), default="batch",
+                    help="batch = configs[1] (white noise, the metric's workload); musical = the same batch shape on seeded MUSICAL "
+                         "signals (detuned notes, percussion, noise floors: tests/tools/musical_check.py) -- white noise is the "
+                         "worst case of the peak picker, music the common one")
     ap.add_argument("--songs", type=int, default=0, help="songs per GPU per step (default: 1024 batch, 6250 mixed, 10000/N library)")
     ap.add_argument("--samples", type=int, default=SONG_SAMPLES, help="samples per song (batch / library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,7 +123,7 @@ def host_cpus():
         return logical, logical
 
 
-def cpu_baseline(global_indices, lengths, features_version=2):
+def cpu_baseline(global_indices, lengths, features_version=2, songs=None):
     """The oracle (C restatement of the reference algorithm, oracle/) on the host cores: the same white-noise songs
     (bit-identical generator), one song per thread at a time (the reference's bulk path runs one Song::analyze per worker
     thread, src/song/decoder.rs:282-329).  TIMED with the baseline-only build (oracle/Makefile `native`: -O3
@@ -131,7 +134,7 @@ def cpu_baseline(global_indices, lengths, features_version=2):
     O = oracle_mod()
     physical, ncpu = host_cpus()
     n = len(global_indices)
-    pcm = np.concatenate([O.white_noise(int(g), int(l)) for g, l in zip(global_indices, lengths)])
+    pcm = np.concatenate(songs if songs is not None else [O.white_noise(int(g), int(l)) for g, l in zip(global_indices, lengths)])
     lens = np.asarray(lengths, np.uint64)
     offs = np.zeros(n, np.uint64)
     offs[1:] = np.cumsum(lens)[:-1]
@@ -151,7 +154,7 @@ def cpu_baseline(global_indices, lengths, features_version=2):
     res = {"value": round(rate, 3), "unit": "songs/sec", "cores": cores, "kind": "port",
            "host_physical_cores": physical, "host_logical_cpus": ncpu,
            "threads_sweep": {str(c): round(r, 2) for r, c in sorted(tried, key=lambda rc: rc[1])},
-           "sample": f"{n} of the same white-noise songs ({int(lens.sum())} samples; spread over the whole batch), "
+           "sample": f"{n} of the same {'white-noise' if songs is None else 'musical'} songs ({int(lens.sum())} samples; spread over the whole batch), "
                      f"oracle/bliss_oracle.c, {fast_note} -- an oracle port, not bliss-rs (rustfft is SIMD mixed-radix); one "
                      f"song per thread, best of the thread-count sweep (threads_sweep) on a host with {physical} physical "
                      f"cores / {ncpu} logical CPUs; default (checker) build: {checker_rate:.1f} songs/s",
@@ -337,7 +340,8 @@ def main():
     scaling = "weak"
     notes = {}
     # ---- the workload: global song list -> this rank's share ----
-    if args.config == "batch":
+    musical_songs = None
+    if args.config in ("batch", "musical"):
         n = args.songs or 1024
         N = args.samples
         lens = np.full(n, N, np.uint64)
@@ -345,6 +349,16 @@ def main():
         n_total = world * n
         workload = (f"configs[1]: batch of {n} synthetic {N}-sample (3-min) white-noise f32 PCM buffers per GPU, full "
                     f"23-feature descriptor set (FeaturesVersion 2)")
+        if args.config == "musical":
+            sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+            from musical_check import musical_batch
+
+            t_gen = time.perf_counter()
+            musical_songs, _meta = musical_batch(n, N, seed=args.seed + rank)
+            workload = (f"the shape of configs[1] on MUSICAL content: {n} synthetic {N}-sample (3-min) songs per GPU from the seeded "
+                        f"generator of tests/tools/musical_check.py (detuned harmonic notes at a random tempo, percussive bursts, "
+                        f"noise floors, gains 1e-3 .. 1; seed {args.seed}), full 23-feature set -- NOT BASELINE's workload (that is "
+                        f"--config batch); generated on the host in {time.perf_counter() - t_gen:.0f} s")
     elif args.config == "library":
         n_total = (args.songs * world) if args.songs else 10000
         N = args.samples
@@ -389,12 +403,16 @@ def main():
     offs[1:] = np.cumsum(padded)[:-1]
     total_samples = int(lens.sum())
     pcm = torch.empty(int(padded.sum()) + 64, dtype=torch.float32, device="cuda")
-    # white noise written straight into HBM; song g of the corpus uses generator index g whatever the rank count
-    ctx.synth_white_noise(pcm, offs, lens, song_index=global_idx)
+    if musical_songs is not None:
+        for o, x in zip(offs, musical_songs):
+            pcm[int(o): int(o) + len(x)] = torch.from_numpy(x).cuda()
+    else:
+        # white noise written straight into HBM; song g of the corpus uses generator index g whatever the rank count
+        ctx.synth_white_noise(pcm, offs, lens, song_index=global_idx)
     out = torch.empty((n, d), dtype=torch.float32, device="cuda")
     status = torch.empty((n,), dtype=torch.int32, device="cuda")
     global_idx_dev = torch.as_tensor(global_idx, device="cuda")  # uploaded once, not per step
-    n_local_max = max(len(s) for s in shards) if args.config != "batch" else n
+    n_local_max = max(len(s) for s in shards) if args.config not in ("batch", "musical") else n
     D_block = None
     if args.config == "library":
         lo, hi = row_block(n_total, rank, world)
@@ -526,7 +544,8 @@ def main():
             "value": round(value, 2), "unit": "songs/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic white noise (Philox4x32-10, uniform [-0.5,0.5)), generated in HBM",
+            "data": ("synthetic white noise (Philox4x32-10, uniform [-0.5,0.5)), generated in HBM" if musical_songs is None else
+                     "synthetic musical signals (seeded generator, tests/tools/musical_check.py), generated on the host, resident in HBM before the timed region"),
             "config": {"workload": workload, "name": args.config, "songs_per_gpu": n, "songs_total": int(job_songs),
                        "samples_per_song": N, "features": d, "chunks_per_step": int(chunks),
                        "parallelism": f"songs sharded x{world}, all-gather of feature rows" if world > 1 else "single GPU"},
@@ -559,7 +578,8 @@ def main():
                 # spread over the whole launch grid (not the first songs of it): every n / cpu_songs-th song
                 k = min(args.cpu_songs, n)
                 picks = [int(i) for i in np.linspace(0, n - 1, k).round().astype(int)]
-            cb, ref = cpu_baseline(global_idx[picks], lens[picks], version)
+            cb, ref = cpu_baseline(global_idx[picks], lens[picks], version,
+                                   songs=[musical_songs[i] for i in picks] if musical_songs is not None else None)
             got = out[picks].cpu().numpy()
             err = np.abs(got - ref)
             cb["checked_songs"] = len(picks)
@@ -587,6 +607,8 @@ def main():
                                                 "GBps": round(pbytes / (kms * 1e-3) / 1e9, 1)}
 
         extras = args.config == "batch" and world == 1
+        if musical_songs is not None:
+            result["config"]["not_the_metric_workload"] = "BASELINE.json's metric is quoted on white noise: --config batch"
 
         # ---- PCIe-inclusive rate of the host-buffer entry points (never `value`) ----
         def section_host_feed():

@@ -324,6 +324,7 @@ int blissgpu_ctx_destroy(blissgpu_ctx* c) {
         (void)hipStreamSynchronize(c->stream);
         if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
         if (c->chr_stream) (void)hipStreamSynchronize(c->chr_stream);
+        if (c->mask_stream) { (void)hipStreamSynchronize(c->mask_stream); (void)hipStreamDestroy(c->mask_stream); }
         for (auto& v : c->events)
             for (auto& ev : v) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
         (void)hipFree(c->tw8192); (void)hipFree(c->tw512); (void)hipFree(c->hann8192); (void)hipFree(c->hannz512);
@@ -806,6 +807,7 @@ int blissgpu_profile_reset(blissgpu_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->aux_stream);
     (void)hipStreamSynchronize(c->chr_stream);
+    if (c->mask_stream) (void)hipStreamSynchronize(c->mask_stream);
     for (auto& v : c->events) {
         for (auto& ev : v) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
         v.clear();
@@ -822,6 +824,7 @@ int blissgpu_profile_get(blissgpu_ctx* c, int k, double* total_ms, uint64_t* lau
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->aux_stream));
     HIP_TRY(hipStreamSynchronize(c->chr_stream));
+    if (c->mask_stream) HIP_TRY(hipStreamSynchronize(c->mask_stream));
     double tot = 0.0;
     for (auto& ev : c->events[k]) {
         float ms = 0.0f;

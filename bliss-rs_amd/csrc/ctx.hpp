@@ -83,6 +83,8 @@ struct ChunkSlot {
     DevBuf<uint8_t> desc;        // SongDesc[] + tile prefix arrays
     PinnedBuf<uint8_t> h_desc;   // pinned staging of desc
     hipEvent_t ev_start = nullptr, ev_fork = nullptr, ev_stft = nullptr, ev_sel = nullptr, ev_tune = nullptr, ev_sum = nullptr, ev_chroma = nullptr;
+    hipEvent_t ev_acf = nullptr, ev_beat = nullptr;  // masked tail (tail_mode >= 2): autocorrelations done / state machines done
+    bool beat_masked = false;              // the chunk in flight ran its beat state machines on the CU-masked stream
     static constexpr int MAX_PIECES = 8;
     hipEvent_t ev_piece[MAX_PIECES] = {};  // the tuning estimate of piece k of the songs is in (split tail)
     int pieces = 0;                        // > 0: the tail of the chunk in flight runs in these pieces
@@ -218,8 +220,11 @@ struct blissgpu_ctx {
     hipStream_t stream = nullptr;      // FFT + chroma chain (the caller-visible stream)
     hipStream_t aux_stream = nullptr;  // per-song tails: PCM statistics, summaries, beat tracker, row assembly
     hipStream_t chr_stream = nullptr;  // tuning estimate of a chunk, beside the next chunk's FFT kernels
+    hipStream_t mask_stream = nullptr; // tail_mode >= 2: a stream confined to `mask_cus` CUs for the beat state machines
+    int mask_cus = 0;
     int tail_mode = -1;                // beat tracker: -1 = beside the FFT-8192 kernel unless the batch is one chunk, 0 / 1 force
-                                       // beside / behind it (BLISSGPU_OPT_TAIL_MODE)
+                                       // beside / behind it; N >= 2: autocorrelations beside it, the state machines beside it on a
+                                       // stream confined to N CUs (BLISSGPU_OPT_TAIL_MODE)
     uint32_t pipeline_chunks = 1;      // cut big batches into at least this many chunks (BLISSGPU_OPT_PIPELINE_CHUNKS; measured: the
                                        // per-song tails have a fixed latency per launch, so more chunks than memory needs lose)
     hipEvent_t ev_interop = nullptr;

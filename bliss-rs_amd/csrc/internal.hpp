@@ -60,17 +60,16 @@ struct SongDesc {
     uint32_t ok;        // 1 = analyse, 0 = too short (status already set by the host)
 };
 
-// Frames whose rolloff bin the FFT-512 kernel could not prove (see its epilogue) are handed to rolloff_fix_kernel: 256
-// magnitudes + the frame's index in the series arrays each.  The record lives in device memory (filled by the host per
-// chunk); the entries borrow the memory of the spectrogram and the peak records, dead until the FFT-8192 kernel starts --
-// room for every frame of the chunk.
+// Frames whose rolloff bin the FFT-512 kernel could not prove (see its epilogue) are handed to rolloff_fix_kernel: the
+// frame's 256 magnitudes at the entry of its own index, and ROLLOFF_UNPROVEN (no rolloff is negative) in its place of the
+// rolloff series, where the exact pass finds it.  The record lives in device memory (filled by the host per chunk); the
+// entries borrow the memory of the spectrogram and the peak records, dead until the FFT-8192 kernel starts -- room for every
+// frame of the chunk.
 struct RollFix {
-    float* mags;        // [cap][256]
-    uint32_t* frame;    // [cap]
-    uint32_t* cursor;   // [0] entries requested (may exceed cap); in a cache line of its own: every unproven frame of the
-                        // launch does an atomic on it, and the record itself is read-only
-    uint32_t cap;
+    float* mags;        // [cap][256]: entry t = the magnitudes of the chunk's timbral frame t (written for unproven frames only)
+    uint32_t cap;       // = the chunk's timbral frames
 };
+constexpr float ROLLOFF_UNPROVEN = -1.0f;
 
 // Per-song scalars produced by the tuning stage.
 struct TuningState {
@@ -157,7 +156,6 @@ struct Workspace {
     float* bt_pre;          // [total_b / 128 + n_songs][BT_PRE_STRIDE] per-run records; song s starts at run b_off / 128 + s
     float* summary;         // [n_songs][16] features 1..9 (zcr, timbral, loudness summaries)
     RollFix* roll_fix;      // the exact rolloff pass's record (see RollFix)
-    uint32_t* roll_fix_cursor;
     size_t roll_fix_bytes;  // the borrowed stretch: spectrogram + peak records
 };
 
@@ -180,6 +178,9 @@ void launch_fft512(const Batch&, const Workspace&, const DeviceTables&, hipStrea
 void launch_rolloff_fix(const Batch&, const Workspace&, uint64_t total_t, hipStream_t);
 void launch_onset(const Batch&, const Workspace&, hipStream_t);
 void launch_beat(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
+// the two halves of launch_beat on streams of their own (the masked tail): autocorrelations (parallel), state machines (a wavefront per song)
+void launch_beat_acf(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
+void launch_beat_track(const Batch&, const Workspace&, const DeviceTables&, hipStream_t);
 void launch_stft8192(const Batch&, const Workspace&, const DeviceTables&, hipStream_t, int shape = 0);  // shape: BLISSGPU_OPT_STFT_SHAPE
 // a contiguous range of a chunk's songs [s0, s1) with the tile / workgroup ranges that belong to it in pfx_ct / pfx_cw
 // units (the tuning estimate and the contraction of a one-chunk batch run in two halves; NULL = the whole chunk)

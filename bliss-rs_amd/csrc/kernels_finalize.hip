@@ -199,48 +199,85 @@ __global__ __launch_bounds__(64) void assemble_kernel(const SongDesc* __restrict
 // for the frames whose bin count the FFT-512 kernel could not prove from its own summation order (a running energy within
 // worst-case rounding of the 95 % threshold).  Thread per frame; this translation unit never fuses a * b + c.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void rolloff_fix_kernel(const RollFix* __restrict__ fix, float* __restrict__ rolloff) {
-    // One wavefront per 64 frames, a lane per frame.  A frame's 256 magnitudes are 1 KB apart from its neighbour's: they
-    // are fetched with coalesced 16-byte loads (four frames x 256 B per instruction) into a padded LDS tile, 64 bins of all
-    // 64 frames at a time, and every lane then walks its own row.  (Keeping all 256 bins of the 64 frames in LDS -- one
-    // read instead of two -- leaves two wavefronts per CU and takes twice as long; 16 whole frames per pass, read once
-    // and contiguously, with 16 walking lanes is slower as well.)
-    __shared__ float tile[64 * 65];
-    const uint32_t n = min(fix->cursor[0], fix->cap);
-    const float* __restrict__ mags = fix->mags;
-    const uint32_t* __restrict__ frame = fix->frame;
+#ifndef RF_STRETCH_FRAMES
+#define RF_STRETCH_FRAMES 1024
+#endif
+constexpr uint32_t RF_STRETCH = RF_STRETCH_FRAMES;  // frames of the rolloff series a wavefront looks through
+
+__global__ __launch_bounds__(64) void rolloff_fix_kernel(const float* __restrict__ mags, float* __restrict__ rolloff, uint32_t n) {
+    // One wavefront per RF_STRETCH frames of the chunk's rolloff series.  It first collects the frames the FFT-512 kernel
+    // left as ROLLOFF_UNPROVEN (a few per cent; their 256 magnitudes wait at the entry of their own index), then takes 64
+    // of them at a time, a lane per frame.  A frame's magnitudes are fetched with coalesced 16-byte loads (four frames x
+    // 256 B per instruction), 64 bins of all 64 frames at a time, and turned through a padded LDS tile (rows of 17 float4:
+    // 16-byte writes and reads, no bank conflicts) so that every lane holds the 64 bins of ITS frame in registers and walks
+    // them there; the loads of the next piece are in flight during the walk.  (Round 6: the walk used to read LDS one float
+    // at a time, each read waited for -- 320 dependent LDS round trips per frame were most of the kernel's time.  Keeping
+    // all 256 bins of the 64 frames in LDS -- one fetch instead of two -- leaves two wavefronts per CU and takes twice as
+    // long; 16 whole frames per pass, read once and contiguously, with 16 walking lanes is slower as well.)
+    __shared__ float4 tile[64 * 17];
+    __shared__ uint32_t list[RF_STRETCH];
     const float freq_per_bin = (float)SAMPLE_RATE / (float)W512;
     const uint32_t lane = threadIdx.x;
-    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {
-        auto load_piece = [&](int p) {
-            __syncthreads();
-            // all 16 loads of the piece in flight together: the wavefront pays the memory latency once per piece (with four
-            // at a time the kernel took 0.25 instead of 0.1 ms per 1024 songs -- the latency, not the walks, was the wait)
-            float4 v[16];
+    const uint32_t first = blockIdx.x * RF_STRETCH;
+    uint32_t count = 0;
+    {
+        float v[RF_STRETCH / 64];  // every load of the stretch in flight together
+#pragma unroll
+        for (uint32_t i = 0; i < RF_STRETCH / 64; i++) {
+            const uint32_t t = first + 64 * i + lane;
+            v[i] = t < n ? rolloff[t] : 0.0f;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < RF_STRETCH / 64; i++) {
+            const bool hit = v[i] == ROLLOFF_UNPROVEN;
+            const uint64_t hits = __ballot(hit);
+            if (hit) list[count + __popcll(hits & ((1ull << lane) - 1))] = first + 64 * i + lane;
+            count += (uint32_t)__popcll(hits);
+        }
+    }
+    __syncthreads();  // the list is complete
+#ifdef RF_SCAN_ONLY  // (timing probe: what the search alone costs)
+    if (count < 4096) return;
+#endif
+    for (uint32_t base = 0; base < count; base += 64) {
+        // piece p of the chunk's 64 frames: 16 loads in flight together (the wavefront pays the memory latency once per piece)
+        auto fetch = [&](int p, float4 (&v)[16]) {
 #pragma unroll
             for (uint32_t q = 0; q < 16; q++) {
-                const uint32_t e = 4 * q + (lane >> 4), f4 = lane & 15;
+                const uint32_t e = base + 4 * q + (lane >> 4), f4 = lane & 15;
                 v[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (base + e < n) v[q] = *reinterpret_cast<const float4*>(mags + (size_t)(base + e) * 256 + 64 * p + 4 * f4);
+                if (e < count) v[q] = *reinterpret_cast<const float4*>(mags + (size_t)list[e] * 256 + 64 * p + 4 * f4);
             }
-#pragma unroll
-            for (uint32_t q = 0; q < 16; q++) {
-                float* t = tile + (4 * q + (lane >> 4)) * 65 + 4 * (lane & 15);
-                t[0] = v[q].x; t[1] = v[q].y; t[2] = v[q].z; t[3] = v[q].w;
-            }
-            __syncthreads();
         };
-        const float* __restrict__ row = tile + lane * 65;
-        float cumsum = 0.0f, upto[4];  // upto[p]: the running sum after piece p -- what `rollsum` will be there as well
+        // through the tile: lane l ends up with bins 64 p .. 64 p + 63 of frame base + l
+        auto turn = [&](const float4 (&v)[16], float4 (&r)[16]) {
+            __syncthreads();  // the tile's last readers are done
+#pragma unroll
+            for (uint32_t q = 0; q < 16; q++) tile[(4 * q + (lane >> 4)) * 17 + (lane & 15)] = v[q];
+            __syncthreads();
+#pragma unroll
+            for (uint32_t q = 0; q < 16; q++) r[q] = tile[lane * 17 + q];
+        };
+        float4 v[16], r[16];
+        float cumsum = 0.0f, upto[3] = {0.0f, 0.0f, 0.0f};  // upto[p]: the running sum after piece p -- what `rollsum` will be there as well
+#pragma unroll 1
         for (int p = 0; p < 4; p++) {
-            load_piece(p);
-#pragma unroll 16
-            for (int j = 0; j < 64; j++) cumsum += row[j] * row[j];
-            upto[p] = cumsum;
+            fetch(p, v);
+            turn(v, r);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                cumsum += r[q].x * r[q].x;
+                cumsum += r[q].y * r[q].y;
+                cumsum += r[q].z * r[q].z;
+                cumsum += r[q].w * r[q].w;
+            }
+            upto[0] = p == 0 ? cumsum : upto[0];
+            upto[1] = p == 1 ? cumsum : upto[1];
+            upto[2] = p == 2 ? cumsum : upto[2];
         }
         // `while rollsum < cumsum && j < len { rollsum += sq[j]; j += 1 }` walks the same partial sums again: it passes
         // every piece whose last partial sum is still below the threshold and stops inside the first other one, so only
-        // that piece has to be walked (and fetched: white noise crosses in the last piece in every lane)
+        // that piece has to be walked (white noise crosses in the last piece in every lane: its bins are still in `r`)
         const float thr = cumsum * 0.95f;
         int pc = 0;
         float rollsum = 0.0f;
@@ -248,28 +285,31 @@ __global__ __launch_bounds__(64) void rolloff_fix_kernel(const RollFix* __restri
         for (int p = 0; p < 3; p++)
             if (upto[p] < thr && pc == p) { pc = p + 1; rollsum = upto[p]; }
         int j = 64 * pc;
-        for (int p = 0; p < 4; p++) {
+        for (int p = 3; p >= 0; p--) {
             if (!__any(pc == p && rollsum < thr)) continue;
-            load_piece(p);
+            if (p != 3) { fetch(p, v); turn(v, r); }
             if (pc == p) {
-#pragma unroll 16
-                for (int q = 0; q < 64; q++) {
-                    const bool go = rollsum < thr;  // monotone: once false it stays false
-                    rollsum = go ? rollsum + row[q] * row[q] : rollsum;
-                    j += go ? 1 : 0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const float sq[4] = {r[q].x * r[q].x, r[q].y * r[q].y, r[q].z * r[q].z, r[q].w * r[q].w};
+#pragma unroll
+                    for (int z = 0; z < 4; z++) {
+                        const bool go = rollsum < thr;  // monotone: once false it stays false
+                        rollsum = go ? rollsum + sq[z] : rollsum;
+                        j += go ? 1 : 0;
+                    }
                 }
             }
         }
         const float bins = cumsum != 0.0f ? (float)j : 0.0f;
-        if (base + lane < n) rolloff[frame[base + lane]] = freq_per_bin * fmaxf(bins, 0.0f);
+        if (base + lane < count) rolloff[list[base + lane]] = freq_per_bin * fmaxf(bins, 0.0f);
     }
 }
 
 void launch_rolloff_fix(const Batch& b, const Workspace& w, uint64_t total_t, hipStream_t st) {
-    if (b.tiles_f == 0) return;
-    // a grid for 1/16 of the frames (a few per cent reach this pass); the loop covers whatever arrived
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(1u << 20, total_t / (16 * 64) + 1);
-    hipLaunchKernelGGL(rolloff_fix_kernel, dim3(blocks), dim3(64), 0, st, w.roll_fix, w.rolloff);
+    if (b.tiles_f == 0 || total_t == 0) return;
+    const uint32_t blocks = (uint32_t)((total_t + RF_STRETCH - 1) / RF_STRETCH);
+    hipLaunchKernelGGL(rolloff_fix_kernel, dim3(blocks), dim3(64), 0, st, w.spec, w.rolloff, (uint32_t)total_t);  // (RollFix::mags = w.spec)
 }
 
 void launch_summary(const Batch& b, const Workspace& w, hipStream_t st) {

@@ -538,14 +538,23 @@ __global__ __launch_bounds__(64) void beat_track_kernel(const SongDesc* __restri
     }
 }
 
-void launch_beat(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
+void launch_beat_acf(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
     if (b.n_songs == 0) return;
     const uint32_t max_runs = b.max_nb >= (uint32_t)BT_STEP ? (b.max_nb - BT_STEP) / BT_STEP + 1 : 0;
     if (max_runs > 0)
         hipLaunchKernelGGL(beat_acf_kernel, dim3(max_runs, b.n_songs), dim3(64), 0, st, b.songs, w.thresholded, t.bt_rwv,
                            w.bt_pre);
+}
+
+void launch_beat_track(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
+    if (b.n_songs == 0) return;
     hipLaunchKernelGGL(beat_track_kernel, dim3(b.n_songs), dim3(64), 0, st, b.songs, w.thresholded, w.e256, t.bt_dfwv,
                        w.bt_pre, w.run_bpm, w.run_cnt, w.runs_pitch, w.tempo);
+}
+
+void launch_beat(const Batch& b, const Workspace& w, const DeviceTables& t, hipStream_t st) {
+    launch_beat_acf(b, w, t, st);
+    launch_beat_track(b, w, t, st);
 }
 
 }  // namespace bg

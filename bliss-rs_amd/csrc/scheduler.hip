@@ -81,18 +81,17 @@ Workspace carve(uint8_t* base, uint32_t ns, const ChunkTotals& t, size_t* bytes)
     w.flux = m.take<float>(t.tot_b); w.thresholded = m.take<float>(t.tot_b);
     w.e256 = m.take<float>(t.tot_e); w.zc256 = m.take<uint32_t>(t.tot_e);
     // The spectrogram and the peak records -- both first written by the FFT-8192 kernel -- lie back to back: until that
-    // kernel starts, the FFT-512 kernel's unproven-rolloff frames borrow the stretch (257 words per entry; consumed by
+    // kernel starts, the FFT-512 kernel's unproven-rolloff frames borrow the stretch (256 words per entry; consumed by
     // rolloff_fix_kernel).  18 412 bytes per chroma frame = 17.9 entries per 2205 samples, and a song has one timbral frame
     // per 128 samples (17.2 per 2205): EVERY frame of the chunk would fit, so no entry is ever turned away.
-    static_assert((size_t)(CBINS_PAD + PIP_MAX_PER_FRAME) * 4 * HOP_T >= (size_t)257 * 4 * HOP_C,
-                  "the borrowed stretch must hold one 257-word entry per timbral frame: bytes per chroma frame x samples per "
+    static_assert((size_t)(CBINS_PAD + PIP_MAX_PER_FRAME) * 4 * HOP_T >= (size_t)256 * 4 * HOP_C,
+                  "the borrowed stretch must hold one 256-word entry per timbral frame: bytes per chroma frame x samples per "
                   "timbral frame >= bytes per entry x samples per chroma frame");
     w.spec = m.take<float>(t.tot_c * CBINS_PAD + 64);
     w.peak_rec = m.take<uint32_t>(t.tot_c * PIP_MAX_PER_FRAME);
     w.roll_fix_bytes = (size_t)(reinterpret_cast<uint8_t*>(w.peak_rec + t.tot_c * PIP_MAX_PER_FRAME) - reinterpret_cast<uint8_t*>(w.spec));
     w.frame_max = m.take<float>(t.tot_c);
     w.roll_fix = m.take<RollFix>(1);
-    w.roll_fix_cursor = m.take<uint32_t>(4);
     w.h1 = m.take<uint32_t>((size_t)ns * H1_BINS); w.hist100 = m.take<uint32_t>((size_t)ns * N_TUNING);
     w.tuning = m.take<TuningState>(ns);
     w.peak_cnt = m.take<uint32_t>(t.tot_c);
@@ -109,9 +108,22 @@ Workspace carve(uint8_t* base, uint32_t ns, const ChunkTotals& t, size_t* bytes)
     return w;
 }
 
+// A stream whose kernels may only run on `cus` of the device's CUs (hipExtStreamCreateWithCUMask).  The driver deals the
+// mask's bits over the XCDs in turn, so the first `cus` bits are cus / 8 CUs on each of the eight.
+int ensure_mask_stream(blissgpu_ctx* c, int cus) {
+    cus = std::max(1, std::min(cus, c->n_cus));
+    if (c->mask_stream && c->mask_cus == cus) return BLISSGPU_OK;
+    if (c->mask_stream) { (void)hipStreamSynchronize(c->mask_stream); (void)hipStreamDestroy(c->mask_stream); c->mask_stream = nullptr; }
+    std::vector<uint32_t> mask((size_t)(c->n_cus + 31) / 32, 0u);
+    for (int i = 0; i < cus; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+    HIP_TRY(hipExtStreamCreateWithCUMask(&c->mask_stream, (uint32_t)mask.size(), mask.data()));
+    c->mask_cus = cus;
+    return BLISSGPU_OK;
+}
+
 int ensure_slot_events(ChunkSlot& s) {
     if (s.ev_free) return BLISSGPU_OK;
-    hipEvent_t* evs[] = {&s.ev_start, &s.ev_fork, &s.ev_stft, &s.ev_sel, &s.ev_tune, &s.ev_sum, &s.ev_chroma, &s.ev_desc, &s.ev_free};
+    hipEvent_t* evs[] = {&s.ev_start, &s.ev_fork, &s.ev_stft, &s.ev_sel, &s.ev_tune, &s.ev_sum, &s.ev_chroma, &s.ev_desc, &s.ev_free, &s.ev_acf, &s.ev_beat};
     for (hipEvent_t* e : evs) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t& e : s.ev_piece) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return BLISSGPU_OK;
@@ -208,13 +220,10 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
         // Every timbral frame of the chunk must have an entry of its own: a frame turned away would keep the unproven
         // fast-path bin without a sign.  The static_assert in carve() proves the bytes-per-sample ratio; this is the
         // per-chunk proof that the rounding of every song's frame counts (many near-minimum-length songs) does not eat it.
-        if ((uint64_t)w.roll_fix_bytes / (257 * 4) < t.tot_t)
+        if ((uint64_t)w.roll_fix_bytes / (256 * 4) < t.tot_t)
             return fail(BLISSGPU_ERR_INVALID, "chunk_front", "internal: the borrowed stretch cannot hold one exact-rolloff entry per timbral frame");
         rf.cap = (uint32_t)t.tot_t;
         rf.mags = w.spec;
-        rf.frame = reinterpret_cast<uint32_t*>(w.spec + (size_t)rf.cap * 256);
-        rf.cursor = w.roll_fix_cursor;
-        HIP_TRY(hipMemsetAsync(w.roll_fix_cursor, 0, 16, st));
         memcpy(h + o, &rf, sizeof(rf));
         HIP_TRY(hipMemcpyAsync(w.roll_fix, h + o, sizeof(rf), hipMemcpyHostToDevice, st));
     }
@@ -238,8 +247,24 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
     // 427 vs 426 ms on the 6 250-song mixed corpus) and keeps the chunk's tail short; a batch of ONE chunk runs it behind
     // the FFT-8192 kernel, where the latency-bound tuning kernels leave the machine half empty (39.5 vs 40.1 ms per 1024
     // songs).
-    const bool beat_late = c->tail_mode == 1 || (c->tail_mode < 0 && only_chunk);
-    if (!beat_late) { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
+    // BLISSGPU_OPT_TAIL_MODE = N >= 2 (round 6 experiment): the autocorrelations (parallel work) here, beside the FFT-8192
+    // kernel, and the state machines -- one wavefront per song, a chain of dependent steps -- beside it as well but on a
+    // stream confined to N CUs: they need residency for a long time, not throughput, so they take N CUs' worth of slots
+    // from the FFT-8192 kernel instead of a share of every CU.
+    slot.beat_masked = multi && c->tail_mode >= 2;
+    if (slot.beat_masked) {
+        if ((rc = ensure_mask_stream(c, c->tail_mode))) return rc;
+        { Prof p(c, K_BEAT, sb); launch_beat_acf(b, w, c->tables, sb); }
+        HIP_TRY(hipEventRecord(slot.ev_acf, sb));
+        HIP_TRY(hipStreamWaitEvent(c->mask_stream, slot.ev_acf, 0));
+        { Prof p(c, K_BEAT, c->mask_stream); launch_beat_track(b, w, c->tables, c->mask_stream); }
+        HIP_TRY(hipEventRecord(slot.ev_beat, c->mask_stream));
+    }
+    // BLISSGPU_OPT_TAIL_MODE = -2 (round 6 experiment): the autocorrelations beside the FFT-8192 kernel, the state machines behind it
+    const bool acf_early = multi && c->tail_mode == -2;
+    if (acf_early) { Prof p(c, K_BEAT, sb); launch_beat_acf(b, w, c->tables, sb); }
+    const bool beat_late = !slot.beat_masked && (c->tail_mode == 1 || acf_early || (c->tail_mode < 0 && only_chunk));
+    if (!beat_late && !slot.beat_masked) { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
     { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st, c->stft_shape); }
     if (multi) {
         HIP_TRY(hipEventRecord(slot.ev_stft, st));
@@ -269,7 +294,7 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
                 HIP_TRY(hipEventRecord(slot.ev_sel, sc));
                 HIP_TRY(hipStreamWaitEvent(sb, slot.ev_sel, 0));
                 Prof p(c, K_BEAT, sb);
-                launch_beat(b, w, c->tables, sb);
+                if (acf_early) launch_beat_track(b, w, c->tables, sb); else launch_beat(b, w, c->tables, sb);
             }
             { Prof p(c, K_TUNE_PASS2, sc); launch_tune_pass2(b, w, sc, &slot.piece[k]); }
             { Prof p(c, K_TUNE_FINAL, sc); launch_tune_final(b, w, sc, &slot.piece[k]); }
@@ -288,7 +313,7 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
             HIP_TRY(hipStreamWaitEvent(sb, slot.ev_sel, 0));
         }
         Prof p(c, K_BEAT, sb);
-        launch_beat(b, w, c->tables, sb);
+        if (acf_early) launch_beat_track(b, w, c->tables, sb); else launch_beat(b, w, c->tables, sb);
     }
     { Prof p(c, K_TUNE_PASS2, sc); launch_tune_pass2(b, w, sc); }
     { Prof p(c, K_TUNE_FINAL, sc); launch_tune_final(b, w, sc); }
@@ -317,6 +342,7 @@ int chunk_back(blissgpu_ctx* c, ChunkSlot& slot, uint32_t features_version, floa
     if (multi) {
         HIP_TRY(hipEventRecord(slot.ev_chroma, st));
         HIP_TRY(hipStreamWaitEvent(sb, slot.ev_chroma, 0));  // aux already holds the chunk's summaries and beat tracker
+        if (slot.beat_masked) HIP_TRY(hipStreamWaitEvent(sb, slot.ev_beat, 0));  // (or the masked stream does)
     }
     { Prof p(c, K_FINALIZE, sb); launch_finalize(slot.batch, slot.ws, features_version, d_out, d_status, c->dbg_tuning.p, c->dbg_nbpms.p, sb); }
     if (multi) HIP_TRY(hipEventRecord(slot.ev_free, sb));
@@ -331,7 +357,7 @@ namespace bg {
 void scheduler_release(blissgpu_ctx* c) {
     for (ChunkSlot& s : c->slot) {
         s.slab.release(); s.desc.release(); s.h_desc.release();
-        hipEvent_t evs[] = {s.ev_start, s.ev_fork, s.ev_stft, s.ev_sel, s.ev_tune, s.ev_sum, s.ev_chroma, s.ev_desc, s.ev_free};
+        hipEvent_t evs[] = {s.ev_start, s.ev_fork, s.ev_stft, s.ev_sel, s.ev_tune, s.ev_sum, s.ev_chroma, s.ev_desc, s.ev_free, s.ev_acf, s.ev_beat};
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : s.ev_piece)

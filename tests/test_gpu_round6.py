@@ -243,7 +243,7 @@ def test_resample_bank_cache_is_bounded_and_evicted_banks_come_back(bliss, oracl
         first = ctx.pcm_decode(d_x, first_rate).cpu().numpy()
         total = 0
         for k in range(30):
-            rate = 500009 + 9973 * k   # no small common factor with 22 050: 1024 phases, 700 - 1100 taps
+            rate = 500009 + 8999 * k   # <= 760 980 Hz (the API's limit is 768 kHz); mostly 1024 phases, 750 - 1140 taps: 100 MiB in all
             got = ctx.pcm_decode(d_x, rate)
             ctx.synchronize()
             taps, phases = oracle.swr_filter(rate)[1].taps, oracle.swr_filter(rate)[1].phase_count

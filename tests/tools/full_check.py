@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--threads", type=int, default=64)
     ap.add_argument("--noise-floor", action="store_true")
     ap.add_argument("--flux-order", type=int, default=0, help="BLISSGPU_OPT_FLUX_ORDER: 1 = SpecFlux summed in the reference's bin order")
+    ap.add_argument("--musical", action="store_true", help="the batch of `bench.py --config musical` (seeded musical signals) instead of white noise")
+    ap.add_argument("--seed", type=int, default=20260927, help="--musical: bench.py's default seed")
     args = ap.parse_args()
     import torch
 
@@ -40,7 +42,17 @@ def main():
     offs = np.arange(n, dtype=np.uint64) * np.uint64(N)
     lens = np.full(n, N, np.uint64)
     pcm = torch.empty(n * N, dtype=torch.float32, device="cuda")
-    ctx.synth_white_noise(pcm, offs, lens, first_song_index=0)
+    meta = None
+    if args.musical:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from musical_check import musical_batch
+
+        songs, meta = musical_batch(n, N, seed=args.seed)
+        for i, x in enumerate(songs):
+            pcm[i * N:(i + 1) * N] = torch.from_numpy(x).cuda()
+        del songs
+    else:
+        ctx.synth_white_noise(pcm, offs, lens, first_song_index=0)
     out, status = ctx.analyze(pcm, offs, lens, 2)
     ctx.synchronize()
     got = out.cpu().numpy()
@@ -89,7 +101,24 @@ def main():
                  "which_side_of_the_floor": {"tempo": side(g64[:, 0], e64[:, 0]), "flatness_mean": side(g64[:, 6], e64[:, 6]),
                                              "flatness_std": side(g64[:, 7], e64[:, 7]),
                                              "all_22_non_tempo_features_max": side(g64[:, 1:].max(axis=1), e64[:, 1:].max(axis=1))}}
-    res = {"songs": n, "samples_per_song": N, "oracle_seconds": round(time.perf_counter() - t0, 1),
+    musical = None
+    if args.musical:
+        # the tuning estimate is the decision music exercises (white noise lands on one tuning): device tuning against the oracle's
+        from concurrent.futures import ThreadPoolExecutor
+
+        def otun(i):
+            return float(O.chroma_desc(pcm[i * N:(i + 1) * N].cpu().numpy())[1])
+
+        with ThreadPoolExecutor(args.threads) as ex:
+            otuning = np.array(list(ex.map(otun, range(n))))
+        bad = np.flatnonzero(np.abs(tuning - otuning) > 1e-12)
+        musical = {"seed": args.seed, "kinds": {str(k): int(sum(m["kind"] == k for m in meta)) for k in range(4)},
+                   "distinct_tunings": int(len(set(np.round(otuning, 2)))), "tuning_mismatches": int(len(bad)),
+                   "tuning_mismatch_songs": [{"song": int(i), **meta[i], "gpu": float(tuning[i]), "oracle": float(otuning[i])} for i in bad[:10]],
+                   "distinct_tempo_values": int(len(set(np.round(ref[:, 0], 4)))),
+                   "songs_without_a_beat": int((ref[:, 0] == -1.0).sum())}
+    res = {"songs": n, "samples_per_song": N, "content": "musical (tests/tools/musical_check.py)" if args.musical else "white noise",
+           "musical": musical, "oracle_seconds": round(time.perf_counter() - t0, 1),
            "tempo_gpu_vs_oracle": tempo_histogram(err[:, 0]), "tempo_noise_floor": noise,
            "max_abs_err_non_tempo": float(err[:, 1:].max()),
            "max_abs_err_per_feature": [float(x) for x in err.max(axis=0)],

@@ -20,9 +20,12 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 SR = 22050
 
 
-def make_song(rng, mods=False):
+def make_song(rng, mods=False, n_samples=None):
     seconds = float(rng.uniform(12.0, 60.0))
     n = int(seconds * SR) + int(rng.integers(0, 2205))
+    if n_samples is not None:   # a fixed length (the bench's three-minute songs): the same draws, then the length is overruled
+        n = int(n_samples)
+        seconds = n / SR
     t = np.arange(n) / SR
     x = np.zeros(n, np.float64)
     cents = float(rng.uniform(-50.0, 50.0))
@@ -85,6 +88,27 @@ def make_song(rng, mods=False):
             m.append("short")
         meta["mods"] = "+".join(m)
     return x.astype(np.float32), meta
+
+
+def _one_of_batch(job):
+    seed, i, n_samples = job
+    x, meta = make_song(np.random.default_rng([int(seed), int(i)]), False, n_samples)
+    return x, meta
+
+
+def musical_batch(n_songs, n_samples, seed=1, procs=None):
+    """n_songs songs of exactly n_samples samples, song i from the generator seeded with (seed, i) -- the same song whatever the
+    batch it is part of -- made by a pool of processes (a three-minute song is a few seconds of numpy).  -> (songs, metas)"""
+    import multiprocessing as mp
+
+    procs = procs or max(1, min(96, (os.cpu_count() or 2) // 2, n_songs))
+    jobs = [(seed, i, n_samples) for i in range(n_songs)]
+    if procs == 1:
+        res = [_one_of_batch(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(procs) as pool:
+            res = pool.map(_one_of_batch, jobs, chunksize=max(1, n_songs // (4 * procs)))
+    return [r[0] for r in res], [r[1] for r in res]
 
 
 def main():
