@@ -142,13 +142,38 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
 #define PW_T_ROWS 32
 #endif
     constexpr int T_ROWS = PW_T_ROWS;  // rows staged per transposed write
+    // (Rounds 3 - 5 staged the tile transposed, st[column][row] with an odd pitch: four lanes to a bank on the storing side, 38 %
+    // of the kernel's LDS cycles.  Three conflict-free forms of THAT tile lost 10 % each -- every one of them paid for its
+    // addresses with vector-ALU instructions, which is what this kernel is short of.  The row-major tile below needs none.)
+#ifndef PW_ST_ROWMAJOR
+#define PW_ST_ROWMAJOR 1   // (0: the transposed staging of rounds 3 - 5, profiles/r06_pairwise_staging_ab.txt)
+#endif
+#ifndef PW_T_UNROLLED
+#define PW_T_UNROLLED 1
+#endif
+#if PW_ST_ROWMAJOR
+    // staged as computed, st[row][column]: a lane's four outputs of a row are 16 consecutive bytes (two 8-byte LDS stores, no
+    // four-lanes-to-a-bank conflicts); the transposition happens on the reading side.  Pitch 258 words: row r starts at bank
+    // 2 r, so the 8 x 8 lanes of a wavefront that assemble eight 128-byte runs (lane = 8 * column + chunk, words at rows
+    // 4 chunk + q) fall on banks 8 chunk + 2 q + column: all different.
+    constexpr int ST_PITCH = PW_COLS + 2;
+#ifndef PW_T_PIPE
+#define PW_T_PIPE 0   // (measured: 10.3 against 9.8 ms, profiles/r06_pairwise_staging_ab.txt)
+#endif
+    // PW_T_PIPE (self-distance kernel): groups of 16 rows, two tiles -- the mirrored stores of group g ride in the row loop
+    // of group g + 1 (one 16-byte piece per row and thread) instead of a phase of their own between two barriers.  Pitch 260
+    // words: rows start 16-byte aligned (one ds_write_b128 per lane and row) at bank 4 r, and the 4 x 16 lanes of a wavefront
+    // that assemble sixteen 64-byte runs (lane = 4 * column + chunk, words at rows 4 chunk + q) fall on banks 16 chunk + 4 q +
+    // column: all different.
+    constexpr bool TPIPE = SYM && PW_T_PIPE;
+    constexpr int TP_ROWS = 16, TP_PITCH = PW_COLS + 4;
+    __shared__ __attribute__((aligned(16))) float st[SYM ? (TPIPE ? 2 * TP_ROWS * TP_PITCH : T_ROWS * ST_PITCH) : 1];
+    auto st_at = [&](int col, int row) -> float& { return st[row * ST_PITCH + col]; };
+#else
     constexpr int T_PITCH = T_ROWS + 1;
-    // (odd pitch: the 8 lanes that assemble one 128-byte run read 8 different banks.  The STORES into this tile are four
-    // lanes to a bank -- 38 % of the kernel's LDS cycles are conflicts -- but the layout without any, word c * 2113 + 33 l +
-    // row for lane l's c-th column, measured 11.2 instead of 10.2 ms in round 4, like the conflict-free layout of round 3:
-    // the LDS is not what this kernel waits for.)
     __shared__ float st[SYM ? PW_COLS : 1][SYM ? T_PITCH : 1];  // staged TRANSPOSED: st[column][row]
     auto st_at = [&](int col, int row) -> float& { return st[col][row]; };
+#endif
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const uint32_t bj = blockIdx.x;  // 256-column block
     bool do_t = false;               // this tile's block lies above the diagonal: it is also written transposed
@@ -281,12 +306,108 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
                 if (j0 + c < m) orow[c] = res[c];
         }
         if (do_t) {
+#if PW_ST_ROWMAJOR
+            f2* d2 = reinterpret_cast<f2*>(__builtin_assume_aligned(&st_at(PW_CPT * lane, r - R0), 8));
+            d2[0] = q0;
+            d2[1] = q1;
+#else
             st_at(PW_CPT * lane + 0, r - R0) = q0.x;
             st_at(PW_CPT * lane + 1, r - R0) = q0.y;
             st_at(PW_CPT * lane + 2, r - R0) = q1.x;
             st_at(PW_CPT * lane + 3, r - R0) = q1.y;
+#endif
         }
     };
+    if constexpr (TPIPE) {
+        const bool aligned = ((ld_out & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+        const bool cols_full = ((uint64_t)bj + 1) * PW_COLS <= m;
+        const int chunk = tid & 3, jcol = tid >> 2;  // this thread's piece of a pass: rows 4 chunk .. 4 chunk + 3 of column 64 pass + jcol
+        bool pend = false;     // a staged group waits for its mirrored stores (workgroup-uniform)
+        int pend_buf = 0;
+        uint64_t pend_first = 0;  // out index of this thread's piece of pass 0 of the waiting group
+        int g = 0;
+        auto piece = [&](int buf, uint64_t first, int pass) __attribute__((always_inline)) {
+            const float* src = st + buf * (TP_ROWS * TP_PITCH) + (4 * chunk) * TP_PITCH + 64 * pass + jcol;
+            f4 v4;
+            v4.x = src[0]; v4.y = src[TP_PITCH]; v4.z = src[2 * TP_PITCH]; v4.w = src[3 * TP_PITCH];
+            __builtin_nontemporal_store(v4, reinterpret_cast<f4*>(__builtin_assume_aligned(out + first + (uint64_t)pass * 64 * ld_out, 16)));
+        };
+        for (int t = 0; t < RT && i0 < n; t++, i0 += PW_ROWS) {
+            const uint32_t bi = (uint32_t)(i0 / PW_COLS);  // block row of this tile
+            if (bi > bj) break;                            // mirrored from the block (bj, bi)
+            do_t = bj > bi;
+            if (t) __syncthreads();  // every wavefront has finished with the previous tile's rows
+            rows_here = (n - i0 < (uint64_t)PW_ROWS) ? n - i0 : (uint64_t)PW_ROWS;
+            for (int e = tid; e < (int)rows_here * D; e += 256) sa[e / D][e % D] = A[i0 * D + e];
+            __syncthreads();
+            if (METRIC == METRIC_COSINE) {
+                if (tid < (int)rows_here) {
+                    const float* a = sa[tid];
+                    sna[tid] = sqrtf(unrolled_dot<D>([&](int k) { return a[k]; }, [&](int k) { return a[k]; }));
+                }
+                __syncthreads();
+            }
+            for (int R0 = 0; R0 < (int)rows_here; R0 += TP_ROWS, g++) {
+                const int buf = g & 1;
+                const int r_end = ((int)rows_here < R0 + TP_ROWS) ? (int)rows_here : R0 + TP_ROWS;
+                const bool whole = r_end - R0 == TP_ROWS;
+                // the waiting group's tile is complete, and nobody still reads the tile this group is about to fill
+                if (pend || do_t) __syncthreads();
+                if (pend && !whole) {  // a ragged group has no four rows per wavefront to carry the pieces: all four now
+#pragma unroll
+                    for (int ps = 0; ps < 4; ps++) piece(pend_buf, pend_first, ps);
+                    pend = false;
+                }
+                float* stb = st + buf * (TP_ROWS * TP_PITCH);
+                int pass = 0;
+#pragma unroll 1
+                for (int r = R0 + wave; r < r_end; r += 4, pass++) {
+                    f2 ap[DP / 2];
+                    load_row(ap, r);
+                    const f2 s0 = row_sum(ap, std::integral_constant<int, 0>{}), s1 = row_sum(ap, std::integral_constant<int, 1>{});
+                    f2 q0, q1;
+                    if (METRIC == METRIC_COSINE) { q0 = finish_fast(s0, 0, r); q1 = finish_fast(s1, 1, r); }
+                    else { q0 = sqrt_rn2(s0); q1 = sqrt_rn2(s1); }
+                    float* orow = out + (i0 + r) * ld_out + j0;
+                    f4 q4;
+                    q4.x = q0.x; q4.y = q0.y; q4.z = q1.x; q4.w = q1.y;
+                    if (vec_ok) {
+                        __builtin_nontemporal_store(q4, reinterpret_cast<f4*>(__builtin_assume_aligned(orow, 16)));
+                    } else {
+                        const float res[PW_CPT] = {q0.x, q0.y, q1.x, q1.y};
+#pragma unroll
+                        for (int c = 0; c < PW_CPT; c++)
+                            if (j0 + c < m) orow[c] = res[c];
+                    }
+                    if (do_t) *reinterpret_cast<f4*>(__builtin_assume_aligned(stb + (r - R0) * TP_PITCH + PW_CPT * lane, 16)) = q4;
+                    if (pend) piece(pend_buf, pend_first, pass);
+                }
+                pend = false;
+                if (do_t) {
+                    if (whole && aligned && cols_full) {
+                        pend = true;
+                        pend_buf = buf;
+                        pend_first = ((uint64_t)bj * PW_COLS + (uint64_t)jcol) * ld_out + i0 + (uint64_t)R0 + 4 * chunk;
+                    } else {  // ragged rows / columns or an unaligned matrix: element by element, between two barriers
+                        __syncthreads();
+                        const int nvalid = r_end - R0;
+                        for (int e = tid; e < PW_COLS * TP_ROWS; e += 256) {
+                            const int j = e / TP_ROWS, rr = e % TP_ROWS;
+                            const uint64_t jrow = (uint64_t)bj * PW_COLS + (uint64_t)j;
+                            if (jrow < m && rr < nvalid) out[jrow * ld_out + i0 + (uint64_t)R0 + rr] = stb[rr * TP_PITCH + j];
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+        if (pend) {
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++) piece(pend_buf, pend_first, ps);
+        }
+        return;
+    }
     for (int t = 0; t < RT && i0 < n; t++, i0 += PW_ROWS) {
     if (SYM) {
         const uint32_t bi = (uint32_t)(i0 / PW_COLS);  // block row of this tile
@@ -349,6 +470,25 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
         const bool fast = nvalid == T_ROWS && ((ld_out & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
         constexpr int LPR = T_ROWS / 4, JPP = 256 / LPR;  // lanes per run of T_ROWS floats, runs per pass of the workgroup
         const int chunk = tid % LPR;
+#if PW_T_UNROLLED
+        // every run of the pass read from the tile back to back, then stored: one LDS round trip per 32-row group instead
+        // of one per run (the loop below waits for each run's words before it stores them)
+        if (fast && ((uint64_t)bj + 1) * PW_COLS <= m) {
+            uint64_t first = ((uint64_t)bj * PW_COLS + (uint64_t)(tid / LPR)) * ld_out + i0 + (uint64_t)R0 + 4 * chunk;
+            asm volatile("" : "+v"(first));  // (computed here, not held across the arithmetic)
+            float* dst = out + first;
+            const uint64_t step = (uint64_t)JPP * ld_out;
+            f4 v4[PW_COLS / JPP];
+#pragma unroll
+            for (int p = 0; p < PW_COLS / JPP; p++) {
+                const int j = JPP * p + tid / LPR;
+                v4[p].x = st_at(j, 4 * chunk); v4[p].y = st_at(j, 4 * chunk + 1); v4[p].z = st_at(j, 4 * chunk + 2); v4[p].w = st_at(j, 4 * chunk + 3);
+            }
+#pragma unroll
+            for (int p = 0; p < PW_COLS / JPP; p++)
+                __builtin_nontemporal_store(v4[p], reinterpret_cast<f4*>(__builtin_assume_aligned(dst + p * step, 16)));
+        } else
+#endif
 #pragma unroll 1   // (unrolled, the eight row pointers are hoisted out of the tile loop and held across the arithmetic: 16 registers)
         for (int p = 0; p < PW_COLS / JPP; p++) {
             const int j = JPP * p + tid / LPR;
