@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
     auto emit_row = [&](int r, int R0, f2 q0, f2 q1) __attribute__((always_inline)) {
         float* orow = out + (i0 + r) * ld_out + j0;
 #ifdef PW_ABL_NO_DSTORE
-        if (q0.x == 12345.678f)
+        if (q0.x != 12345.678f) {
+        } else
 #endif
         if (vec_ok) {
             f4 q4;
@@ -305,7 +306,11 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
             for (int c = 0; c < PW_CPT; c++)
                 if (j0 + c < m) orow[c] = res[c];
         }
+#ifdef PW_ABL_NO_STAGE   // (ablation: wrong results, the cost of the LDS stores of the staging)
+        if (do_t && q0.x == 12345.678f) {
+#else
         if (do_t) {
+#endif
 #if PW_ST_ROWMAJOR
             f2* d2 = reinterpret_cast<f2*>(__builtin_assume_aligned(&st_at(PW_CPT * lane, r - R0), 8));
             d2[0] = q0;
@@ -463,7 +468,9 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
         }
     }
     if (do_t) {  // workgroup-uniform
+#ifndef PW_ABL_NO_TBARRIER   // (ablation: wrong results, the cost of the two barriers around the mirrored stores)
         __syncthreads();
+#endif
         // mirrored block: its row bj * 256 + j holds the staged column j, 32 consecutive outputs = one 128-byte run,
         // assembled by 8 consecutive lanes (16 bytes each) so that every store instruction writes whole lines
         const int nvalid = ((int)rows_here - R0 < T_ROWS) ? (int)rows_here - R0 : T_ROWS;
@@ -486,6 +493,9 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
             }
 #pragma unroll
             for (int p = 0; p < PW_COLS / JPP; p++)
+#ifdef PW_ABL_NO_TSTORE
+                if (v4[p].x == 12345.678f)
+#endif
                 __builtin_nontemporal_store(v4[p], reinterpret_cast<f4*>(__builtin_assume_aligned(dst + p * step, 16)));
         } else
 #endif
@@ -508,7 +518,9 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
                     if (4 * chunk + q < nvalid) dst[q] = st_at(j, 4 * chunk + q);
             }
         }
+#ifndef PW_ABL_NO_TBARRIER
         __syncthreads();
+#endif
     }
     }
     }

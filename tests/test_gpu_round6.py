@@ -316,3 +316,84 @@ def test_the_three_big_kernels_are_not_slower_than_recorded():
     print("kernel: measured min ms, recorded min ms:", report)
     for k, (now, then) in report.items():
         assert now <= 1.06 * then, (k, now, then)
+
+
+def test_bench_musical_config_runs_and_checks_itself_against_the_oracle():
+    """`bench.py --config musical` (round 5 review: one realistic-content line): the batch shape of configs[1] on the seeded
+    musical generator, same JSON contract, its in-run oracle check on every song of a small batch -- tempo within the
+    reference's 1e-5 (src/song/mod.rs:582-590), the twenty features that are not flatness within 1e-5 (flatness of a
+    noise-free tonal song sits on FFT rounding noise: test_random_musical_songs_vs_oracle holds it to the oracle's own
+    f32-vs-f64 distance), and the line says that it is not the metric's workload."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "musical", "--songs", "12", "--samples", "661500",
+                          "--steps", "2", "--warmup", "1", "--cpu-songs", "12", "--no-pairwise", "--no-host-feed", "--no-playlist",
+                          "--no-small-calls"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["config"]["name"] == "musical" and "not_the_metric_workload" in r["config"] and r["data"].startswith("synthetic musical")
+    assert r["unit"] == "songs/sec" and r["value"] > 0 and r["roofline"]["kernels_ms_per_step"]["fft512_kernel"] > 0
+    cb = r["cpu_baseline"]
+    assert cb["checked_songs"] == 12 and "musical" in cb["sample"]
+    assert cb["tempo_abs_err"]["over_1e-5"] == 0, cb["tempo_abs_err"]
+    assert cb["max_abs_err_vs_gpu_non_tempo"] < 2e-4, cb   # flatness floor; every other feature is checked song by song elsewhere
+
+
+def test_unproven_rolloff_frames_find_their_way_whatever_the_chunking(bliss):
+    """Round 6: an unproven frame's 256 magnitudes wait at the entry of the frame's OWN index in the borrowed stretch and a
+    sentinel in the rolloff series marks it (no slot counter, no list).  The stretch is per chunk: the same songs cut into
+    one, a few and many chunks (other frame indices, other entries) and with every frame forced through the exact pass must give the
+    same rows and the same per-frame rolloff series bit for bit -- and no sentinel may survive in any series."""
+    import os
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "tools"))
+    import musical_check
+
+    rng = np.random.default_rng(77)
+    songs = [musical_check.make_song(rng, mods=(i % 3 == 0))[0] for i in range(20)]
+    lens = np.array([len(s) for s in songs], np.uint64)
+    padded = (lens + np.uint64(63)) // np.uint64(64) * np.uint64(64)
+    offs = np.zeros(len(songs), np.uint64)
+    offs[1:] = np.cumsum(padded)[:-1]
+    buf = np.zeros(int(padded.sum()) + 64, np.float32)
+    for s, o in zip(songs, offs):
+        buf[int(o):int(o) + len(s)] = s
+    pcm = torch.from_numpy(buf).cuda()
+
+    def run(ws_limit, exact_all):
+        c = bliss.Context(0)
+        if ws_limit:
+            c.set_workspace_limit(ws_limit)   # 0.2 MB of scratch per second of audio: the batch (~ 720 s) needs ~ 150 MB
+        c.set_option("rolloff_exact_all", exact_all)
+        out, status = c.analyze(pcm, offs, lens, 2)
+        c.synchronize()
+        rows = out.cpu().numpy()
+        n_chunks = c.last_chunks()
+        c.close()
+        return rows, n_chunks
+
+    base, n1 = run(0, 0)
+    assert n1 == 1
+    c = bliss.Context(0)
+    out, _ = c.analyze(pcm, offs, lens, 2)
+    c.synchronize()
+    series = [c.debug_fetch("rolloff", i) for i in range(len(songs))]
+    c.close()
+    assert all((s >= 0.0).all() for s in series), "a ROLLOFF_UNPROVEN sentinel survived"
+    assert sum(len(s) for s in series) > 400000
+    seen = set()
+    for ws_limit, exact_all in ((96 << 20, 0), (32 << 20, 0), (0, 1), (32 << 20, 1)):
+        rows, n = run(ws_limit, exact_all)
+        seen.add(n)
+        assert np.array_equal(rows.view(np.uint32), base.view(np.uint32)), (ws_limit, exact_all, n)
+    assert len(seen) >= 3 and max(seen) >= 4, seen   # one chunk, a few, many

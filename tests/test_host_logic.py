@@ -544,3 +544,19 @@ def test_decoded_song_struct_is_the_same_in_c_rust_and_ctypes():
     assert [(n, t) for n, t in _ffi.DecodedSong._fields_] == [("pcm", C.c_void_p), ("frames", C.c_uint64), ("sample_rate", C.c_uint32),
                                                              ("channels", C.c_uint16), ("sample_format", C.c_uint16)]
     assert C.sizeof(_ffi.DecodedSong) == 24
+
+
+def test_musical_bench_batch_is_seeded_per_song():
+    """`bench.py --config musical` / full_check.py --musical: song i of the batch comes from the generator seeded with (seed, i)
+    -- the same samples whatever the batch size or the number of generating processes, so that a 1024-song oracle check and a
+    128-song spot check talk about the same songs."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    from musical_check import make_song, musical_batch
+
+    a, ma = musical_batch(3, 30000, seed=5, procs=1)
+    b, mb = musical_batch(5, 30000, seed=5, procs=2)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b[:3])) and ma == mb[:3]
+    x, _ = make_song(np.random.default_rng([5, 2]), False, 30000)
+    assert x.dtype == np.float32 and len(x) == 30000 and np.array_equal(x, a[2])
+    c, _ = musical_batch(1, 30000, seed=6, procs=1)
+    assert not np.array_equal(c[0], a[0])
