@@ -25,6 +25,16 @@
 #include "device_utils.hpp"
 #include "internal.hpp"
 
+// store flavours of the two halves of a self-distance block (1 = non-temporal, the shipped form; 0 = plain: measured in
+// profiles/r06_pairwise_staging_ab.txt)
+#ifndef PW_NT_DIRECT
+#define PW_NT_DIRECT 1
+#endif
+#ifndef PW_NT_MIRROR
+#define PW_NT_MIRROR 1
+#endif
+#define PW_STORE4(NT, value, ptr) do { if (NT) __builtin_nontemporal_store((value), (ptr)); else *(ptr) = (value); } while (0)
+
 namespace bg {
 
 constexpr int PW_ROWS = 128, PW_COLS = 256, PW_CPT = 4;  // tile rows, tile cols, cols per thread
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
         if (vec_ok) {
             f4 q4;
             q4.x = q0.x; q4.y = q0.y; q4.z = q1.x; q4.w = q1.y;
-            __builtin_nontemporal_store(q4, reinterpret_cast<f4*>(__builtin_assume_aligned(orow, 16)));  // written once, never re-read here
+            PW_STORE4(PW_NT_DIRECT, q4, reinterpret_cast<f4*>(__builtin_assume_aligned(orow, 16)));  // written once, never re-read here
         } else {
             const float res[PW_CPT] = {q0.x, q0.y, q1.x, q1.y};
 #pragma unroll
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
 #ifdef PW_ABL_NO_TSTORE
                 if (v4[p].x == 12345.678f)
 #endif
-                __builtin_nontemporal_store(v4[p], reinterpret_cast<f4*>(__builtin_assume_aligned(dst + p * step, 16)));
+                PW_STORE4(PW_NT_MIRROR, v4[p], reinterpret_cast<f4*>(__builtin_assume_aligned(dst + p * step, 16)));
         } else
 #endif
 #pragma unroll 1   // (unrolled, the eight row pointers are hoisted out of the tile loop and held across the arithmetic: 16 registers)

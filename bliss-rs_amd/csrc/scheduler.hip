@@ -263,8 +263,12 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
     // BLISSGPU_OPT_TAIL_MODE = -2 (round 6 experiment): the autocorrelations beside the FFT-8192 kernel, the state machines behind it
     const bool acf_early = multi && c->tail_mode == -2;
     if (acf_early) { Prof p(c, K_BEAT, sb); launch_beat_acf(b, w, c->tables, sb); }
-    const bool beat_late = !slot.beat_masked && (c->tail_mode == 1 || acf_early || (c->tail_mode < 0 && only_chunk));
-    if (!beat_late && !slot.beat_masked) { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
+    // BLISSGPU_OPT_TAIL_MODE = -3: the whole beat tracker BESIDE THE CONTRACTION (behind the tuning estimate): the contraction waits for
+    // memory with its vector ALUs a fifth busy, the autocorrelations are arithmetic and the state machines latency -- and the
+    // tuning chain, the only thing between the FFT-8192 kernel and the contraction, gets the machine to itself.
+    const bool beat_last = multi && c->tail_mode == -3;
+    const bool beat_late = !slot.beat_masked && !beat_last && (c->tail_mode == 1 || acf_early || (c->tail_mode < 0 && only_chunk));
+    if (!beat_late && !slot.beat_masked && !beat_last) { Prof p(c, K_BEAT, sb); launch_beat(b, w, c->tables, sb); }
     { Prof p(c, K_STFT8192); launch_stft8192(b, w, c->tables, st, c->stft_shape); }
     if (multi) {
         HIP_TRY(hipEventRecord(slot.ev_stft, st));
@@ -300,6 +304,11 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
             { Prof p(c, K_TUNE_FINAL, sc); launch_tune_final(b, w, sc, &slot.piece[k]); }
             HIP_TRY(hipEventRecord(slot.ev_piece[k], sc));
         }
+        if (beat_last) {
+            HIP_TRY(hipStreamWaitEvent(sb, slot.ev_piece[slot.pieces - 1], 0));
+            Prof p(c, K_BEAT, sb);
+            launch_beat(b, w, c->tables, sb);
+        }
         HIP_TRY(hipGetLastError());
         slot.back_pending = true;
         return BLISSGPU_OK;
@@ -318,6 +327,11 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
     { Prof p(c, K_TUNE_PASS2, sc); launch_tune_pass2(b, w, sc); }
     { Prof p(c, K_TUNE_FINAL, sc); launch_tune_final(b, w, sc); }
     if (multi) HIP_TRY(hipEventRecord(slot.ev_tune, sc));
+    if (beat_last) {
+        HIP_TRY(hipStreamWaitEvent(sb, slot.ev_tune, 0));
+        Prof p(c, K_BEAT, sb);
+        launch_beat(b, w, c->tables, sb);
+    }
     HIP_TRY(hipGetLastError());
     slot.back_pending = true;
     return BLISSGPU_OK;
