@@ -89,8 +89,10 @@ int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
 /* Scheduling knobs of ONE context for the measurement tools and the tests (the library reads no environment variable for
  * them; defaults are what production uses).  Synchronises the context's stream. */
 #define BLISSGPU_OPT_SERIAL 0           /* 1: every kernel on one stream, nothing overlaps (clean per-kernel timings) */
-#define BLISSGPU_OPT_TAIL_MODE 1        /* beat tracker: -1 auto (default), 0 beside / 1 behind the FFT-8192 kernel; N >= 2: beside it, the
-                                           per-song state machines on a stream confined to N compute units */
+#define BLISSGPU_OPT_TAIL_MODE 1        /* beat tracker: -1 auto (default), 0 beside / 1 behind the FFT-8192 kernel.  Measurement forms of
+                                           round 6 (same rows; none wins, profiles/r06_tail_mask_ab.txt): N >= 2 beside it with the
+                                           per-song state machines on a stream confined to N compute units; -2 only the
+                                           autocorrelations beside it; -3 the whole tracker beside the chroma contraction */
 #define BLISSGPU_OPT_PIPELINE_CHUNKS 2  /* cut big batches into at least this many chunks (default 1) */
 #define BLISSGPU_OPT_CAND_BUDGET 3      /* tuning-candidate pool: slots per chroma frame (default 48; 0 starves the pool) */
 #define BLISSGPU_OPT_ROLLOFF_EXACT_ALL 4 /* 1: every frame's rolloff bin through the reference-order pass, not only the frames
