@@ -104,7 +104,7 @@ struct ChunkSlot {
 #ifndef FEED_COPY_STREAMS
 #define FEED_COPY_STREAMS 2
 #endif
-// the staging ring's default shape (measured: tests/tools/stage_sweep.py, profiles/r06_stage_sweep.txt)
+// the staging ring's default shape (measured: tests/tools/stage_sweep.py, profiles/r06_stage_sweep_first.txt)
 #ifndef STAGE_LANES_DEFAULT
 #define STAGE_LANES_DEFAULT 4
 #endif

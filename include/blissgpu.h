@@ -124,7 +124,7 @@ int blissgpu_ctx_synchronize(blissgpu_ctx *ctx);
                                            local_cpulist of its PCI function; a no-op on a one-node host); 0 (default): wherever
                                            the scheduler puts them -- near the caller's buffers, which measured better: a worker
                                            reading the caller's memory across the socket link is slower than the DMA engine
-                                           reading the slab across it (profiles/r06_stage_sweep.txt) */
+                                           reading the slab across it (profiles/r06_stage_numa_ab.txt) */
 int blissgpu_ctx_set_option(blissgpu_ctx *ctx, int option, int64_t value);
 /* Bytes of pageable host PCM this context has staged through its pinned ring since it was created (0: every source so far
  * was page-locked, small, or the ring is switched off). */
