@@ -54,6 +54,12 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 __device__ __forceinline__ f2 splat(float x) { f2 r; r.x = x; r.y = x; return r; }
+// an index every lane of the wavefront computed alike, moved to scalar registers: with a 32-bit lane offset on top the store
+// takes the `saddr + voffset` form and no lane keeps a 64-bit address (two VGPRs each) across the arithmetic
+__device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
 
 // Correctly rounded sqrt (what Rust's f32::sqrt / the oracle's sqrtf return) for the two halves of a pair.
 // v_sqrt_f32 is within 1 ulp; the exact residuals against the two neighbours (one FMA each) pick the correctly
@@ -301,7 +307,12 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
         return lo < 0x0F800000u - 1u;
     };
     auto emit_row = [&](int r, int R0, f2 q0, f2 q1) __attribute__((always_inline)) {
-        float* orow = out + (i0 + r) * ld_out + j0;
+#ifndef PW_SADDR
+#define PW_SADDR 1
+#endif
+        // (self-distance form: r is the wavefront's row in a scalar register, the row pointer scalar arithmetic + the lane's 16 bytes)
+        float* orow = (SYM && PW_SADDR) ? out + wave_uniform((i0 + r) * ld_out + (uint64_t)bj * PW_COLS) + (uint32_t)(lane * PW_CPT)
+                                        : out + (i0 + r) * ld_out + j0;
 #ifdef PW_ABL_NO_DSTORE
         if (q0.x != 12345.678f) {
         } else
@@ -434,7 +445,13 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
     // stage the row tile and, for cosine, the row norms
     if (t) __syncthreads();  // every wavefront has finished with the previous tile's rows
     rows_here = (n - i0 < (uint64_t)PW_ROWS) ? n - i0 : (uint64_t)PW_ROWS;
-    for (int e = tid; e < (int)rows_here * D; e += 256) sa[e / D][e % D] = A[i0 * D + e];
+    {
+        // (the thread index made opaque per tile: otherwise the per-lane 64-bit source pointer of this loop is computed once, kept
+        // across the arithmetic of all eight tiles -- and spilled, at three wavefronts per SIMD; see PW_DRAIN_BEFORE_GROUPS)
+        int t0 = tid;
+        if (SYM) asm volatile("" : "+v"(t0));
+        for (int e = t0; e < (int)rows_here * D; e += 256) sa[e / D][e % D] = A[i0 * D + e];
+    }
     __syncthreads();
     if (METRIC == METRIC_COSINE) {
         if (tid < (int)rows_here) {
@@ -443,10 +460,21 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
         }
         __syncthreads();
     }
+    // The wavefront's index in a SCALAR register, re-made per tile: everything derived from it (the LDS address of its rows, the
+    // row pointer of its direct stores) is then scalar arithmetic per row instead of per-lane 64-bit values computed once and
+    // kept -- at three wavefronts per SIMD those were spilled, and the compiler's wait for a reloaded value sat inside the group
+    // loop as `s_waitcnt vmcnt(0)`; on gfx950 that counter also holds the wavefront's STORES, so every 32 rows a wavefront stood
+    // still until the 16 KiB it had just written were acknowledged by memory.
+    int wave_u = wave;
+    if (SYM) {
+        int w = wave;
+        asm volatile("" : "+v"(w));  // (opaque: re-made in this tile, not hoisted to the top of the kernel and carried)
+        wave_u = __builtin_amdgcn_readfirstlane(w);
+    }
     for (int R0 = 0; R0 < (int)rows_here; R0 += T_ROWS) {
     {
         const int r_end = ((int)rows_here < R0 + T_ROWS) ? (int)rows_here : R0 + T_ROWS;
-        int r = R0 + wave;
+        int r = R0 + wave_u;
         if (PIPELINED) {
             // two rows per trip, in ONE basic block: the first row's square roots are independent of the second row's 136
             // packed operations (and its LDS reads of the first row's last differences), so the scheduler overlaps them
@@ -490,10 +518,18 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
 #if PW_T_UNROLLED
         // every run of the pass read from the tile back to back, then stored: one LDS round trip per 32-row group instead
         // of one per run (the loop below waits for each run's words before it stores them)
-        if (fast && ((uint64_t)bj + 1) * PW_COLS <= m) {
+        if (fast && ((uint64_t)bj + 1) * PW_COLS <= m && ld_out < (1ull << 26)) {  // (32 rows x ld_out floats stay below 2^32 bytes)
+#if PW_SADDR
+            // uniform part in scalar registers, the lane's part (row tid / LPR of the pass, four floats at 4 * chunk) in 32 bits
+            int t1 = tid;
+            asm volatile("" : "+v"(t1));  // (the lane's offset computed here, not once and held -- spilled -- across the arithmetic)
+            const uint32_t lane_off = (uint32_t)(t1 / LPR) * (uint32_t)ld_out + 4u * (uint32_t)(t1 % LPR);
+            float* dst = out + wave_uniform((uint64_t)bj * PW_COLS * ld_out + i0 + (uint64_t)R0) + lane_off;
+#else
             uint64_t first = ((uint64_t)bj * PW_COLS + (uint64_t)(tid / LPR)) * ld_out + i0 + (uint64_t)R0 + 4 * chunk;
             asm volatile("" : "+v"(first));  // (computed here, not held across the arithmetic)
             float* dst = out + first;
+#endif
             const uint64_t step = (uint64_t)JPP * ld_out;
             f4 v4[PW_COLS / JPP];
 #pragma unroll
