@@ -16,6 +16,19 @@ __global__ void k(const float* x, float* y, size_t n) {
     if (i < n) y[i] = __builtin_amdgcn_sqrtf(x[i]);
 }
 
+// every non-negative finite f32 (bit patterns 0 .. 0x7F800000, denormal inputs included) against its successor: the number of
+// places where v_sqrt_f32 DEcreases.  0 = monotone, so the maximum of a set of magnitudes is the root of the largest power --
+// what lets stft8192_kernel take one root for the frame maximum of the bins it stores as powers (internal.hpp, SPEC_POWER_FROM).
+__global__ void k_monotone(unsigned long long* decreases, unsigned int* first_bad) {
+    const uint32_t stride = gridDim.x * 256u;
+    unsigned long long bad = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x; b < 0x7F800000ull; b += stride) {
+        const float lo = __builtin_amdgcn_sqrtf(__uint_as_float((uint32_t)b)), hi = __builtin_amdgcn_sqrtf(__uint_as_float((uint32_t)b + 1u));
+        if (!(hi >= lo)) { bad++; atomicMin(first_bad, (uint32_t)b); }
+    }
+    if (bad) atomicAdd(decreases, bad);
+}
+
 static void report(const char* what, const std::vector<float>& x, const std::vector<float>& y) {
     size_t same = 0, one = 0, more = 0;
     double se_hw = 0, se_rn = 0;
@@ -56,5 +69,14 @@ int main() {
     k<<<(unsigned)((N + 255) / 256), 256>>>(dx, dy, N);
     hipMemcpy(y.data(), dy, N * 4, hipMemcpyDeviceToHost);
     report("every float of [1, 4)", x, y);
-    return 0;
+    unsigned long long* d_bad; unsigned int* d_first;
+    unsigned long long bad = 0; unsigned int first = 0xFFFFFFFFu;
+    hipMalloc(&d_bad, 8); hipMalloc(&d_first, 4);
+    hipMemcpy(d_bad, &bad, 8, hipMemcpyHostToDevice); hipMemcpy(d_first, &first, 4, hipMemcpyHostToDevice);
+    k_monotone<<<4096, 256>>>(d_bad, d_first);
+    hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost); hipMemcpy(&first, d_first, 4, hipMemcpyDeviceToHost);
+    printf("monotone sweep over every non-negative finite f32 (2139095040 neighbours): v_sqrt_f32 decreases at %llu places%s\n", bad,
+           bad ? "" : " -- monotone");
+    if (bad) printf("  first at bit pattern 0x%08x\n", first);
+    return bad ? 1 : 0;
 }
