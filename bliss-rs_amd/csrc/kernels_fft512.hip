@@ -90,6 +90,37 @@ __device__ __forceinline__ float row16_scan_incl(float v) {  // row_shr:n with z
     return v;
 }
 
+// Several row reductions at once, the chains interleaved by hand.  Left to the compiler, two float reductions issued together are
+// paired by the SLP vectoriser into v_pk_add_f32 -- which takes no DPP operand, so every step becomes two v_mov_b32_dpp + one
+// packed add per PAIR (three instructions where two v_add_f32_dpp do) -- and a single chain pays two wait states between a DPP
+// read and the add that wrote its source.  Interleaved, every DPP source was written at least three instructions earlier (the
+// leading s_nop covers whatever instruction stands in front of the block: hazards inside an asm statement are not the
+// compiler's).  dpp(v) + v is v + dpp(v): the same bits as row16_sum / row16_scan_incl.
+#define BG_DPP_STEP(OP, DST, SRC, CTRL) OP " " DST ", " SRC ", " SRC " " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+// a, b, d: row totals of the inputs in every lane; c: inclusive scan along the row (row_shr with zero fill).  The first step
+// writes the results' registers from the inputs', so an input that stays live costs no copy.
+__device__ __forceinline__ void row16_sum3_scan1(float in_a, float in_b, float in_c, float in_d, float& a, float& b, float& c, float& d) {
+    asm("s_nop 1\n\t"
+        BG_DPP_STEP("v_add_f32_dpp", "%0", "%4", "quad_perm:[1,0,3,2]") BG_DPP_STEP("v_add_f32_dpp", "%1", "%5", "quad_perm:[1,0,3,2]")
+        BG_DPP_STEP("v_add_f32_dpp", "%2", "%6", "row_shr:1") BG_DPP_STEP("v_add_f32_dpp", "%3", "%7", "quad_perm:[1,0,3,2]")
+        BG_DPP_STEP("v_add_f32_dpp", "%0", "%0", "quad_perm:[2,3,0,1]") BG_DPP_STEP("v_add_f32_dpp", "%1", "%1", "quad_perm:[2,3,0,1]")
+        BG_DPP_STEP("v_add_f32_dpp", "%2", "%2", "row_shr:2") BG_DPP_STEP("v_add_f32_dpp", "%3", "%3", "quad_perm:[2,3,0,1]")
+        BG_DPP_STEP("v_add_f32_dpp", "%0", "%0", "row_half_mirror") BG_DPP_STEP("v_add_f32_dpp", "%1", "%1", "row_half_mirror")
+        BG_DPP_STEP("v_add_f32_dpp", "%2", "%2", "row_shr:4") BG_DPP_STEP("v_add_f32_dpp", "%3", "%3", "row_half_mirror")
+        BG_DPP_STEP("v_add_f32_dpp", "%0", "%0", "row_mirror") BG_DPP_STEP("v_add_f32_dpp", "%1", "%1", "row_mirror")
+        BG_DPP_STEP("v_add_f32_dpp", "%2", "%2", "row_shr:8") BG_DPP_STEP("v_add_f32_dpp", "%3", "%3", "row_mirror")
+        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+        : "v"(in_a), "v"(in_b), "v"(in_c), "v"(in_d));
+}
+// two float row totals and an integer one, three chains (a DPP source written two instructions earlier: exactly the two wait
+// states the read needs), in place
+#define BG_DPP3(CTRL)                                                                                           \
+    BG_DPP_STEP("v_add_f32_dpp", "%0", "%0", CTRL) BG_DPP_STEP("v_add_f32_dpp", "%1", "%1", CTRL) BG_DPP_STEP("v_add_u32_dpp", "%2", "%2", CTRL)
+__device__ __forceinline__ void row16_sum2f_1u(float& a, float& b, uint32_t& c) {
+    asm("s_nop 1\n\t" BG_DPP3("quad_perm:[1,0,3,2]") BG_DPP3("quad_perm:[2,3,0,1]") BG_DPP3("row_half_mirror") BG_DPP3("row_mirror")
+        : "+v"(a), "+v"(b), "+v"(c));
+}
+
 struct FrameMags {
     float m[16];  // |X[16l + e]|
     float nyq;    // |X[256]| (every lane)
@@ -216,7 +247,7 @@ __device__ __forceinline__ void stats128(const f2 r0, const f2 r1, const f2 r2, 
     constexpr uint64_t LOW = 0x0001000100010001ull;  // lane 0 of the four 16-lane groups
     const uint64_t x0 = __ballot(r0.x > 0.0f), y0 = __ballot(r0.y > 0.0f), x1 = __ballot(r1.x > 0.0f), y1 = __ballot(r1.y > 0.0f);
     const uint64_t x2 = __ballot(r2.x > 0.0f), y2 = __ballot(r2.y > 0.0f), x3 = __ballot(r3.x > 0.0f), y3 = __ballot(r3.y > 0.0f);
-    const uint64_t yb = __ballot(before.y > 0.0f), start = __ballot(song_start);
+    const uint64_t yb = __ballot(before.y > 0.0f), start = __builtin_amdgcn_ballot_w64(song_start);
     auto shifted = [&](uint64_t y, uint64_t prev_bits) { return ((y << 1) & ~LOW) | prev_bits; };
     const uint64_t p0 = (((yb >> 15) & ~start) | (x0 & start)) & LOW;
     add_lane_bit(zc, x0 ^ y0);
@@ -276,6 +307,16 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
     // k0 + 1 is B against A), frames k0 + 2 and k0 + 3 into A (flux: A against B).
     FrameMags A, B;
     const bool active = k_begin < (long)sd.n_f;
+    // Inside the frame loop a frame is named by its position r in the group (k = k_begin + r, r = 0 .. 31: the loop counter, the
+    // same in every lane) and every bound is a lane constant relative to k_begin: the 64-bit frame index cost an add and a
+    // 64-bit compare per test, five of each per frame.
+    const int len = active ? (int)(k_end - k_begin) : 0;                                                      // frames of this group
+    const long left_t = (long)sd.n_t - k_begin, left_b = (long)sd.n_b - (k_begin >> 1);
+    const int lim_t = left_t < 0 ? 0 : (left_t > FRAMES_PER_GROUP ? FRAMES_PER_GROUP : (int)left_t);          // r < lim_t <=> k < n_t
+    const int lim_b = left_b < 0 ? 0 : (left_b > FRAMES_PER_GROUP ? FRAMES_PER_GROUP : (int)left_b);          // (r - 1) / 2 < lim_b <=> q < n_b
+    const bool at_song_start = k_begin == 0;
+    // lane offset of rows 12..15 of frame k_begin + 1 (r = 0 loads them for r + 1); frame r adds 512 r bytes as a scalar offset
+    const uint32_t xoff0 = (uint32_t)(((k_begin + 2) * HOP_T - HOP_T - base + 2 * l) * 4);
     f2 raw[16];
     // The flux of a group's first tempo frame (FFT frame k_begin + 1) needs the magnitudes of the tempo frame before it,
     // FFT frame k_begin - 1 -- the last frame of the group before.  Only the first group of a workgroup transforms that
@@ -302,27 +343,27 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
     const float freq_per_bin = (float)SAMPLE_RATE / (float)W512;
 
     // one frame of the unrolled body: J = position in the body (k = kb + J), CUR / PREV = the magnitude sets as above
-    auto frame = [&](auto jc, long k, FrameMags& cur, FrameMags& prev) {
+    auto frame = [&](auto jc, int r, FrameMags& cur, FrameMags& prev) {
         constexpr int J = decltype(jc)::value;
         constexpr int R = (4 * J) & 15;
-        stats128(row<R>(raw, 12), row<R>(raw, 13), row<R>(raw, 14), row<R>(raw, 15), row<R>(raw, 11), k == 0, ss_acc, zc_acc);
+        stats128(row<R>(raw, 12), row<R>(raw, 13), row<R>(raw, 14), row<R>(raw, 15), row<R>(raw, 11), at_song_start && r == 0, ss_acc, zc_acc);
         __builtin_amdgcn_sched_barrier(0);
         fft512_compute<R>(raw, l, tile, tabs, cur);
-        if (k + 1 < k_end) {
+        if (r + 1 < len) {
             // rows 12..15 of frame k + 1 = samples [(k + 1) * 128, (k + 2) * 128) replace this frame's rows 0..3; issued a
-            // whole frame ahead, so their latency is off the critical path.  (The lane offset addresses the row itself: a
-            // negative frame start must not wrap the 32-bit lane offset, the descriptor's range check does not see the
-            // scalar offset.)
-            const uint32_t xoff = (uint32_t)(((k + 2) * HOP_T - HOP_T - base + 2 * l) * 4);
+            // whole frame ahead, so their latency is off the critical path.  (Never before the song's first sample, so nothing
+            // here relies on the descriptor's range check, which does not see the scalar offset.)
+            const uint32_t soff = (uint32_t)r * (uint32_t)(HOP_T * 4);
 #pragma unroll
-            for (int n1 = 0; n1 < 4; n1++) row<R>(raw, n1) = buf_load_f2(r_x, xoff, 128u * n1);
+            for (int n1 = 0; n1 < 4; n1++) row<R>(raw, n1) = buf_load_f2(r_x, xoff0, soff + 128u * n1);
         }
         if (J & 1) {
             // 256-sample block q = (k - 1) / 2 is complete: reduce over the 16 lanes, lane 0 writes
-            const float ss = row16_sum(ss_acc);
-            const uint32_t zc = (uint32_t)row16_sum((int)zc_acc);
-            const long q = (k - 1) >> 1;
-            if (l == 0) { e256[sd.e_off + q] = ss; zc256[sd.e_off + q] = zc; }
+            // (block energy, crossings and -- in the default order -- the flux: one interleaved block of three row reductions)
+            float ss = ss_acc;
+            uint32_t zc = zc_acc;
+            const int qr = (r - 1) >> 1;  // q = k_begin / 2 + qr
+            const long q = (k_begin >> 1) + qr;
             ss_acc = 0.0f;
             zc_acc = 0;
             // tempo frame j = (k-1)/2 : SpecFlux over bins 0..256 (src/aubio.rs:455-467)
@@ -345,22 +386,25 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
                 }
             }
             f = __shfl(f, (threadIdx.x & 48) + 15, 64) + fmaxf(cur.nyq - prev.nyq, 0.0f);  // lane 15's total, then bin 256
+            ss = row16_sum(ss);
+            zc = (uint32_t)row16_sum((int)zc);
             } else {
 #pragma unroll
             for (int e = 0; e < 16; e++) f += fmaxf(cur.m[e] - prev.m[e], 0.0f);
             if (l == 0) f += fmaxf(cur.nyq - prev.nyq, 0.0f);
-            f = row16_sum(f);
+            row16_sum2f_1u(ss, f, zc);
             }
-            if (J == 1 && share && k == k_begin + 1) {
+            if (l == 0) { e256[sd.e_off + q] = ss; zc256[sd.e_off + q] = zc; }
+            if (J == 1 && share && r == 1) {
                 // no previous tempo frame here: hand this frame's magnitudes to the group before
 #pragma unroll
                 for (int e = 0; e < 16; e++) halo[grp][16 * e + l] = cur.m[e];
                 if (l == 0) halo[grp][256] = cur.nyq;
-            } else if (l == 0 && q < (long)sd.n_b) {
+            } else if (l == 0 && qr < lim_b) {
                 flux[sd.b_off + q] = f;
             }
         }
-        if (k < (long)sd.n_t) {
+        if (r < lim_t) {
             // the 256-bin vector the reference's timbral path sees: bin 255 := |Re X[256]| (src/aubio.rs:240-261)
             const float m15 = (l == 15) ? cur.nyq : cur.m[15];
             // sum m, sum e m (e = bin index inside the lane) and sum m^2, two bins per packed instruction
@@ -374,8 +418,10 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
             }
             const float sum = s2.x + s2.y, sqsum = q2.x + q2.y;
             const float wsum = (float)(16 * l) * sum + (e2.x + e2.y);  // sum (16 l + e) m_e
-            const float total = row16_sum(sum);
-            const float wtotal = row16_sum(wsum);
+            // the frame's four float reductions in one interleaved block (row16_sum3_scan1): total, weighted total, and -- for the
+            // rolloff below -- the inclusive scan and the total of the lanes' energies
+            float total, wtotal, incl, cum_total;
+            row16_sum3_scan1(sum, wsum, sqsum, sqsum, total, wtotal, incl, cum_total);
             // spectral_rolloff (src/aubio.rs:36-58): bins consumed until the running energy reaches 95 %.  The reference
             // adds the 256 squares one by one in f32; here a lane scan supplies the energy below the lane's first bin and
             // the lane walks its 16 bins.  A bin COUNT is discontinuous in those sums, so the two orders must not be
@@ -385,8 +431,6 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
             // squares and the walk (u = 2^-24) -- hands its 256 magnitudes to rolloff_fix_kernel, which repeats the
             // reference's loop literally (about 2 % of white-noise frames; every other frame's count is provably the
             // sequential one).
-            const float incl = row16_scan_incl(sqsum);
-            const float cum_total = row16_sum(sqsum);
             const float thr = cum_total * 0.95f;
             float d = (incl - sqsum) - thr;
             float near = FLT_MAX;
@@ -428,10 +472,10 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
             // The scalar tail (two divisions, log2, exp2, the normalisations: ~40 instructions) would run identically on all
             // 16 lanes of the group; instead lane k mod 16 keeps the reduced sums of frame k and every 16 frames each lane
             // finishes ITS frame -- one pass of the scalar tail serves 16 frames, and the three stores become coalesced.
-            const bool mine = l == ((int)k & 15);
+            const bool mine = l == (r & 15);  // (k_begin is a multiple of 32)
             // an unproven frame (any of the group's 16 lanes within the guard) is marked in the packed integers: its rolloff
             // leaves this kernel as ROLLOFF_UNPROVEN and rolloff_fix_kernel finds it there
-            const uint64_t risky_lanes = __ballot(risky);
+            const uint64_t risky_lanes = __builtin_amdgcn_ballot_w64(risky);  // (the builtin: __ballot of a combined condition is lowered to v_cndmask + v_cmp)
             const uint32_t grp_mask = (uint32_t)(risky_lanes >> (threadIdx.x & 48)) & 0xFFFFu;
             // packed integers: rolloff count (9 bits) | any zero group (bit 9) | zero energy (bit 10) | exponent sum (16 bits
             // from bit 11) | unproven (bit 27)
@@ -450,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
                     // was 11 % slower than on noise).
                     // (the stretch is named by a record in memory, read only here: a kernel argument would live in SGPRs
                     // through the whole frame loop, which has none to spare)
-                    float4* dst = reinterpret_cast<float4*>(fix->mags + (size_t)(sd.t_off + (uint64_t)k) * 256 + 16 * l);
+                    float4* dst = reinterpret_cast<float4*>(fix->mags + (size_t)(sd.t_off + (uint64_t)(k_begin + r)) * 256 + 16 * l);
                     dst[0] = make_float4(cur.m[0], cur.m[1], cur.m[2], cur.m[3]);
                     dst[1] = make_float4(cur.m[4], cur.m[5], cur.m[6], cur.m[7]);
                     dst[2] = make_float4(cur.m[8], cur.m[9], cur.m[10], cur.m[11]);
@@ -460,9 +504,10 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
         }
     };
     // finish the frames [k16, k16 + 16) whose sums the lanes hold (lane l: frame k16 + l)
-    auto finish16 = [&](long k16) {
-        const long k = k16 + l;
-        if (k < k_end && k < (long)sd.n_t) {
+    auto finish16 = [&](int r16) {
+        const int r = r16 + l;
+        const long k = k_begin + r;
+        if (r < len && r < lim_t) {
             // spectral_centroid (src/aubio.rs:16-29) then bin_to_freq (:68-71)
             const float cbin = (st_total == 0.0f) ? 0.0f : st_wtotal / st_total;
             const int st_c = st_ints & 511, st_exps = (st_ints >> 11) & 0xFFFF;
@@ -478,16 +523,16 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
         }
     };
 
-    for (long kb = k_begin; kb < k_end; kb += 4) {
-        frame(std::integral_constant<int, 0>{}, kb, B, A);
+    for (int rb = 0; rb < len; rb += 4) {
+        frame(std::integral_constant<int, 0>{}, rb, B, A);
         __builtin_amdgcn_sched_barrier(0);  // keep the frames apart: interleaving two of them costs more registers than it hides
-        if (kb + 1 < k_end) frame(std::integral_constant<int, 1>{}, kb + 1, B, A);
+        if (rb + 1 < len) frame(std::integral_constant<int, 1>{}, rb + 1, B, A);
         __builtin_amdgcn_sched_barrier(0);
-        if (kb + 2 < k_end) frame(std::integral_constant<int, 2>{}, kb + 2, A, B);
+        if (rb + 2 < len) frame(std::integral_constant<int, 2>{}, rb + 2, A, B);
         __builtin_amdgcn_sched_barrier(0);
-        if (kb + 3 < k_end) frame(std::integral_constant<int, 3>{}, kb + 3, A, B);
+        if (rb + 3 < len) frame(std::integral_constant<int, 3>{}, rb + 3, A, B);
         __builtin_amdgcn_sched_barrier(0);
-        if ((kb & 15) == 12 || kb + 4 >= k_end) finish16(kb & ~15L);  // 16 frames stashed, or the group's last frames
+        if ((rb & 15) == 12 || rb + 4 >= len) finish16(rb & ~15);  // 16 frames stashed, or the group's last frames
     }
 
     // ---- the flux of the NEXT group's first tempo frame (FFT frame k_begin + 33) against this group's last one (k_begin +
