@@ -94,21 +94,25 @@ __device__ __forceinline__ void radix16(f2 (&v)[16]) {
 // Real-input split for a 2M-point real FFT packed as an M-point complex FFT (z[n] = x[2n] + i x[2n+1]):
 // with zk = Z[k], zm = Z[(M-k) % M], w = exp(-2*pi*i*k/(2M)):
 //     X[k] = (A + P) / 2,   X[M-k] = conj(A - P) / 2,   A = zk + conj(zm),  P = w * (-i) * (zk - conj(zm))
-// Returns the squared magnitudes |A + P|^2 and |A - P|^2 (4 x the true ones); 8 packed instructions + 2 adds.
+// Returns the squared magnitudes |A + P|^2 and |A - P|^2 (4 x the true ones); 9 packed instructions.  The two results are built
+// side by side -- U = (Re(A + P), Re(A - P)), V = (Im(A + P), Im(A - P)), U U + V V -- so the sum of the two squares is one
+// packed add for both bins (until round 6: X1 = A + P, X2 = A - P, their packed squares, and a scalar add each; the same
+// operations on the same operands, one instruction more).
 __device__ __forceinline__ void split_pair_sq(f2 zk, f2 zm, f2 w, float& sq_k, float& sq_mirror) {
-    f2 a, b, t, p, x1, x2;
+    f2 a, b, t, p, u, v;
     asm("v_pk_add_f32 %0, %6, %7 neg_hi:[0,1]\n\t"                                   // A = zk + conj(zm)
         "v_pk_add_f32 %1, %6, %7 neg_lo:[0,1]\n\t"                                   // B = zk - conj(zm)
         "v_pk_mul_f32 %2, %1, %8 op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"      // t = (B.x*w.y, -B.x*w.x)
         "v_pk_fma_f32 %3, %1, %8, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"           // P = (B.y*w.x, B.y*w.y) + t
-        "v_pk_add_f32 %4, %0, %3\n\t"                                                // X1 = A + P
-        "v_pk_add_f32 %5, %0, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"                       // X2 = A - P
+        "v_pk_add_f32 %4, %0, %3 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"      // U = (A.x + P.x, A.x - P.x)
+        "v_pk_add_f32 %5, %0, %3 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"      // V = (A.y + P.y, A.y - P.y)
         "v_pk_mul_f32 %4, %4, %4\n\t"
-        "v_pk_mul_f32 %5, %5, %5"
-        : "=&v"(a), "=&v"(b), "=&v"(t), "=&v"(p), "=&v"(x1), "=&v"(x2)
+        "v_pk_mul_f32 %5, %5, %5\n\t"
+        "v_pk_add_f32 %4, %4, %5"                                                     // (|A + P|^2, |A - P|^2)
+        : "=&v"(a), "=&v"(b), "=&v"(t), "=&v"(p), "=&v"(u), "=&v"(v)
         : "v"(zk), "v"(zm), "v"(w));
-    sq_k = x1.x + x1.y;
-    sq_mirror = x2.x + x2.y;
+    sq_k = u.x;
+    sq_mirror = u.y;
 }
 
 // single-bin form: |A + P|^2 only; 6 packed instructions + 1 add

@@ -343,8 +343,11 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
     const float freq_per_bin = (float)SAMPLE_RATE / (float)W512;
 
     // one frame of the unrolled body: J = position in the body (k = kb + J), CUR / PREV = the magnitude sets as above
-    auto frame = [&](auto jc, int r, FrameMags& cur, FrameMags& prev) {
+    auto frame = [&](auto jc, int r_lane, FrameMags& cur, FrameMags& prev) {
         constexpr int J = decltype(jc)::value;
+        // (the counter of a loop whose exit diverges lives in a vector register although every lane holds the same value:
+        // taken as a scalar, the tests against it, `r & 15` and the row loads' scalar offset are scalar operands)
+        const int r = __builtin_amdgcn_readfirstlane(r_lane);
         constexpr int R = (4 * J) & 15;
         stats128(row<R>(raw, 12), row<R>(raw, 13), row<R>(raw, 14), row<R>(raw, 15), row<R>(raw, 11), at_song_start && r == 0, ss_acc, zc_acc);
         __builtin_amdgcn_sched_barrier(0);
