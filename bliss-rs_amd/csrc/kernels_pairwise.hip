@@ -300,12 +300,22 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
         q.y = sqrt_rn_fast(sum.y);
         return q;
     };
-    auto is_tiny = [&](f2 a, f2 b) __attribute__((always_inline)) -> bool {  // v_sqrt_f32 does not take denormal inputs: sums below 2^-96 (and not 0) go the long way
+    // v_sqrt_f32 does not take denormal inputs: a row with a sum below 2^-96 goes the long way (sqrtf), wave-uniformly.  The test
+    // is one unsigned minimum over the four bit patterns -- x in [0, 2^-96) <=> bits(x) < bits(2^-96); inf / NaN / negative sums are
+    // large -- and lets ZERO take the long way too (it comes out right there, and a zero distance is a duplicate song: rare).
+    // Only the diagonal blocks of a self-distance matrix hold a zero in every row; there (zero_is_common, workgroup-uniform) the
+    // test excludes it as rounds 3 - 6 did everywhere: x in (0, 2^-96) <=> bits(x) - 1 < bits(2^-96) - 1, a subtraction per sum.
+    bool zero_is_common = false;
+    auto is_tiny = [&](f2 a, f2 b) __attribute__((always_inline)) -> bool {
         if (METRIC == METRIC_COSINE) return false;
-        // x in (0, 2^-96)  <=>  bits(x) - 1 < bits(2^-96) - 1 as unsigned (0 wraps to the top, inf / NaN are large)
-        const uint32_t lo = min(min(__float_as_uint(a.x) - 1u, __float_as_uint(a.y) - 1u), min(__float_as_uint(b.x) - 1u, __float_as_uint(b.y) - 1u));
-        return lo < 0x0F800000u - 1u;
+        if (zero_is_common) {
+            const uint32_t lo = min(min(__float_as_uint(a.x) - 1u, __float_as_uint(a.y) - 1u), min(__float_as_uint(b.x) - 1u, __float_as_uint(b.y) - 1u));
+            return lo < 0x0F800000u - 1u;
+        }
+        const uint32_t lo = min(min(__float_as_uint(a.x), __float_as_uint(a.y)), min(__float_as_uint(b.x), __float_as_uint(b.y)));
+        return lo < 0x0F800000u;
     };
+    auto slow_roots = [&](f2 s) __attribute__((always_inline)) -> f2 { f2 q; q.x = sqrtf(s.x); q.y = sqrtf(s.y); return q; };
     auto emit_row = [&](int r, int R0, f2 q0, f2 q1) __attribute__((always_inline)) {
 #ifndef PW_SADDR
 #define PW_SADDR 1
@@ -441,6 +451,7 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
 #ifndef PW_ABL_NO_T   // (ablation builds, tests/tools/variant_obj.sh: what each phase of the self-distance kernel costs)
         do_t = bj > bi;
 #endif
+        zero_is_common = bi == bj;
     }
     // stage the row tile and, for cosine, the row norms
     if (t) __syncthreads();  // every wavefront has finished with the previous tile's rows
@@ -489,8 +500,7 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
                 f2 qb0 = finish_fast(sb0, 0, r + 4), qb1 = finish_fast(sb1, 1, r + 4);
                 const bool tiny = is_tiny(sa0, sa1) || is_tiny(sb0, sb1);
                 if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {  // wave-uniform, next to never
-                    qa0.x = sqrtf(sa0.x); qa0.y = sqrtf(sa0.y); qa1.x = sqrtf(sa1.x); qa1.y = sqrtf(sa1.y);
-                    qb0.x = sqrtf(sb0.x); qb0.y = sqrtf(sb0.y); qb1.x = sqrtf(sb1.x); qb1.y = sqrtf(sb1.y);
+                    qa0 = slow_roots(sa0); qa1 = slow_roots(sa1); qb0 = slow_roots(sb0); qb1 = slow_roots(sb1);
                 }
                 emit_row(r, R0, qa0, qa1);
                 emit_row(r + 4, R0, qb0, qb1);
@@ -501,8 +511,9 @@ __global__ __launch_bounds__(256, (METRIC == METRIC_EUCLIDEAN ? 3 : 2)) void pai
             f2 ap[DP / 2];
             load_row(ap, r);
             const f2 s0 = row_sum(ap, std::integral_constant<int, 0>{}), s1 = row_sum(ap, std::integral_constant<int, 1>{});
-            if (METRIC == METRIC_COSINE) emit_row(r, R0, finish_fast(s0, 0, r), finish_fast(s1, 1, r));
-            else emit_row(r, R0, sqrt_rn2(s0), sqrt_rn2(s1));
+            f2 q0 = finish_fast(s0, 0, r), q1 = finish_fast(s1, 1, r);
+            if (__builtin_expect(__ballot(is_tiny(s0, s1)) != 0ull, 0)) { q0 = slow_roots(s0); q1 = slow_roots(s1); }  // wave-uniform; ONE test per row
+            emit_row(r, R0, q0, q1);
         }
     }
     if (do_t) {  // workgroup-uniform
