@@ -39,6 +39,21 @@ __device__ __forceinline__ void radix4_pk(f2& v0, f2& v1, f2& v2, f2& v3) {
         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(d));
 }
 
+// the same butterfly on (v0, v1, -i v2, v3): the multiplication by -i rides in the modifiers of the two instructions that read
+// v2 (the W_16^4 twiddle of the radix-16 pass costs nothing), 8 instructions
+__device__ __forceinline__ void radix4_pk_v2mi(f2& v0, f2& v1, f2& v2, f2& v3) {
+    f2 t0, t1, t2, d;
+    asm("v_pk_add_f32 %4, %0, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"   // t0 = v0 + (-i) v2
+        "v_pk_add_f32 %5, %0, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"   // t1 = v0 - (-i) v2
+        "v_pk_add_f32 %6, %1, %3\n\t"                                            // t2 = v1 + v3
+        "v_pk_add_f32 %7, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"                   // d  = v1 - v3
+        "v_pk_add_f32 %0, %4, %6\n\t"                                            // o0 = t0 + t2
+        "v_pk_add_f32 %2, %4, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"                   // o2 = t0 - t2
+        "v_pk_add_f32 %1, %5, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"   // o1 = t1 + (-i) d
+        "v_pk_add_f32 %3, %5, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"       // o3 = t1 - (-i) d
+        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(d));
+}
+
 // a * w, 2 instructions
 __device__ __forceinline__ f2 cmul_pk(f2 a, f2 w) {
     f2 t, r;
@@ -70,7 +85,7 @@ __device__ __forceinline__ f2 mul_mi_pk(f2 a, f2 ones) {
 // index with R16(k) instead of paying register moves.
 __host__ __device__ constexpr int R16(int k) { return 4 * (k & 3) + (k >> 2); }
 
-// forward 16-point DFT, in place: v[R16(k)] <- sum_n v[n] * exp(-2*pi*i*n*k/16); 81 instructions
+// forward 16-point DFT, in place: v[R16(k)] <- sum_n v[n] * exp(-2*pi*i*n*k/16); 80 instructions
 __device__ __forceinline__ void radix16(f2 (&v)[16]) {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
     // layer 1: for each b, radix-4 over a on v[4a + b]  -> u[b][c] stored back at v[4c + b]
@@ -81,14 +96,16 @@ __device__ __forceinline__ void radix16(f2 (&v)[16]) {
     v[6] = cmul_pk_s(v[6], mk(R2, -R2));     // W^2
     v[7] = cmul_pk_s(v[7], mk(S1, -C1));     // W^3
     v[9] = cmul_pk_s(v[9], mk(R2, -R2));     // W^2
-    v[10] = mul_mi_pk(v[10], mk(1.0f, 1.0f));  // W^4 = -i
+    // (v[10] *= W^4 = -i: folded into its butterfly below)
     v[11] = cmul_pk_s(v[11], mk(-R2, -R2));  // W^6
     v[13] = cmul_pk_s(v[13], mk(S1, -C1));   // W^3
     v[14] = cmul_pk_s(v[14], mk(-R2, -R2));  // W^6
     v[15] = cmul_pk_s(v[15], mk(-C1, S1));   // W^9
     // layer 2: for each c, radix-4 over b on v[4c + b] -> X[c + 4d] at v[4c + d]
-#pragma unroll
-    for (int c = 0; c < 4; c++) radix4_pk(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    radix4_pk(v[0], v[1], v[2], v[3]);
+    radix4_pk(v[4], v[5], v[6], v[7]);
+    radix4_pk_v2mi(v[8], v[9], v[10], v[11]);
+    radix4_pk(v[12], v[13], v[14], v[15]);
 }
 
 // Real-input split for a 2M-point real FFT packed as an M-point complex FFT (z[n] = x[2n] + i x[2n+1]):

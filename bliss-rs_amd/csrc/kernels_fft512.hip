@@ -392,8 +392,13 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
             ss = row16_sum(ss);
             zc = (uint32_t)row16_sum((int)zc);
             } else {
+            // (the differences two bins per packed subtraction; the sum in the same order as bin by bin)
 #pragma unroll
-            for (int e = 0; e < 16; e++) f += fmaxf(cur.m[e] - prev.m[e], 0.0f);
+            for (int i = 0; i < 8; i++) {
+                const f2 d = mk(cur.m[2 * i], cur.m[2 * i + 1]) - mk(prev.m[2 * i], prev.m[2 * i + 1]);
+                f += fmaxf(d.x, 0.0f);
+                f += fmaxf(d.y, 0.0f);
+            }
             if (l == 0) f += fmaxf(cur.nyq - prev.nyq, 0.0f);
             row16_sum2f_1u(ss, f, zc);
             }
