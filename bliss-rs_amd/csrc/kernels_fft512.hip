@@ -424,8 +424,11 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
                 e2 = e2 + mp * mk((float)(2 * i), (float)(2 * i + 1));
                 q2 = q2 + mp * mp;
             }
-            const float sum = s2.x + s2.y, sqsum = q2.x + q2.y;
-            const float wsum = (float)(16 * l) * sum + (e2.x + e2.y);  // sum (16 l + e) m_e
+            // (the three horizontal adds as opaque instructions: left to the SLP vectoriser two of them become ONE packed add behind
+            // three register moves that line the halves up)
+            auto hadd = [](f2 v) __attribute__((always_inline)) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(v.x), "v"(v.y)); return r; };
+            const float sum = hadd(s2), sqsum = hadd(q2);
+            const float wsum = (float)(16 * l) * sum + hadd(e2);  // sum (16 l + e) m_e
             // the frame's four float reductions in one interleaved block (row16_sum3_scan1): total, weighted total, and -- for the
             // rolloff below -- the inclusive scan and the total of the lanes' energies
             float total, wtotal, incl, cum_total;
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
             // sequential one).
             const float thr = cum_total * 0.95f;
             float d = (incl - sqsum) - thr;
-            float near = FLT_MAX;
+            float near;
             uint32_t signs = 0;  // sign bit of d after each bin, shifted in: d < 0 <=> that bin is still below the threshold
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -450,7 +453,8 @@ __global__ __launch_bounds__(256, 2) void fft512_kernel(const float* __restrict_
                 d = fmaf(m1, m1, d0);
                 signs = __builtin_amdgcn_alignbit(signs, __float_as_uint(d0), 31);  // (signs << 1) | (d0 < 0)
                 signs = __builtin_amdgcn_alignbit(signs, __float_as_uint(d), 31);
-                asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(near) : "v"(d0), "v"(d));
+                if (i == 0) asm("v_min_f32 %0, |%1|, |%2|" : "=v"(near) : "v"(d0), "v"(d));  // (no FLT_MAX to load first)
+                else asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(near) : "v"(d0), "v"(d));
             }
             // not (near > guard): also catches NaN; totals in the denormal range have no relative bound; a frame of digital
             // silence is 0 in either order
