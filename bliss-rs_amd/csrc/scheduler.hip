@@ -234,12 +234,14 @@ int chunk_front(blissgpu_ctx* c, ChunkSlot& slot, const float* d_pcm, SongDesc* 
     HIP_TRY(hipMemsetAsync(w.cand_cursor, 0, 16, st));
     { Prof p(c, K_FFT512); launch_fft512(b, w, c->tables, st, c->rolloff_exact_all, c->flux_order); }
     { Prof p(c, K_ROLLFIX); launch_rolloff_fix(b, w, t.tot_t, st); }
-    { Prof p(c, K_ONSET); launch_onset(b, w, st); }
     // tails: the reference runs them as the tempo / timbral / loudness threads of src/song/mod.rs:432-491
     if (multi) {
         HIP_TRY(hipEventRecord(slot.ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(sb, slot.ev_fork, 0));
     }
+    // (the peak picker heads the aux stream: only the beat tracker reads its series, and on the main stream its 70 us stood
+    // between the exact-rolloff pass -- which must leave the borrowed spectrogram stretch first -- and the FFT-8192 kernel)
+    { Prof p(c, K_ONSET, sb); launch_onset(b, w, sb); }
     { Prof p(c, K_SUMMARY, sb); launch_summary(b, w, sb); }
     // The beat tracker (the parallel autocorrelation kernel + the one-wavefront-per-song state machine): beside the
     // FFT-8192 kernel its workgroups displace FFT-8192 workgroups (that kernel fills the LDS and the register file:
