@@ -328,6 +328,12 @@ def test_frame_and_tile_boundary_lengths(ctx, oracle):
         for delta in (-1, 0, 1):
             if base + delta >= 8192:
                 lengths.add(base + delta)
+    # the FFT-512 kernel names a frame by its position in a 32-frame lane group and tests it against the group's own limits (round
+    # 6): timbral frame counts n_t on and either side of group and tile edges, with the remainder r that decides whether the
+    # tempo path adds one more FFT frame than the timbral path has (n - 512 = 256 q + r: n_t = 2 q + 1 or 2 q + 2, 2 n_b = 2 q + 2)
+    for n_t in (63, 64, 65, 95, 96, 97, 127, 128, 129, 511, 512, 513, 543, 544, 545, 1023, 1024, 1025):
+        for r in (0, 127):
+            lengths.add(128 * (n_t - 1) + 512 + r)
     lengths = sorted(lengths)
     songs = [oracle.white_noise(700 + i, n) for i, n in enumerate(lengths)]
     got, status = _run(ctx, songs)
